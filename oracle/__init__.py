@@ -1,0 +1,309 @@
+"""ORACLE — test infrastructure only.
+
+ctypes loader for ``oracle/liboracle.so`` (the C restatement of the reference's CPU algorithms).
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py`` may import this
+package, and only as the checker; nothing under ``winterfell_amd/`` imports it.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+H_BLAKE3_F64 = 0
+H_RP64 = 1
+
+M = 0xFFFFFFFF00000001
+
+
+def build(force=False):
+    """Compile the oracle with gcc (build, not use)."""
+    if force or not os.path.exists(_LIB_PATH):
+        subprocess.check_call(["make", "-C", _HERE, "-s"] + (["-B"] if force else []))
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            build()
+        _lib = ctypes.CDLL(_LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_u64 = ctypes.c_uint64
+_p = ctypes.c_void_p
+
+
+def _declare(l):
+    for name in ("or_f64_mul1", "or_f64_add1", "or_f64_sub1", "or_f64_exp1"):
+        getattr(l, name).restype = _u64
+        getattr(l, name).argtypes = [_u64, _u64]
+    for name in ("or_f64_inv1", "or_f64_new1", "or_f64_as_int1"):
+        getattr(l, name).restype = _u64
+        getattr(l, name).argtypes = [_u64]
+    l.or_f64_root_of_unity1.restype = _u64
+    l.or_f64_root_of_unity1.argtypes = [ctypes.c_uint]
+    l.or_permute_index.restype = _u64
+    l.or_permute_index.argtypes = [_u64, _u64]
+    l.or_f64_poly_eval.restype = _u64
+    l.or_f64_poly_eval.argtypes = [_p, _u64, _u64]
+    l.or_row_width.restype = _u64
+    l.or_row_width.argtypes = [_u64]
+    l.or_partition_size.restype = _u64
+    l.or_partition_size.argtypes = [_u64, _u64, ctypes.c_uint, _u64]
+    l.or_num_partitions.restype = _u64
+    l.or_num_partitions.argtypes = [_u64, _u64, ctypes.c_uint, _u64]
+    l.or_merkle_build.restype = ctypes.c_int
+    l.or_merkle_build_par.restype = ctypes.c_int
+    l.or_build_trace_commitment.restype = ctypes.c_int
+
+
+def _ptr(a):
+    return ctypes.c_void_p(a.ctypes.data)
+
+
+def _u64arr(a):
+    return np.ascontiguousarray(a, dtype=np.uint64)
+
+
+# ---- field helpers --------------------------------------------------------------------------------
+def f64_from_int(vals):
+    a = _u64arr(vals)
+    out = np.empty_like(a)
+    lib().or_f64_from_int(_ptr(a), _ptr(out), _u64(a.size))
+    return out
+
+
+def f64_to_int(vals):
+    a = _u64arr(vals)
+    out = np.empty_like(a)
+    lib().or_f64_to_int(_ptr(a), _ptr(out), _u64(a.size))
+    return out
+
+
+def f64_new(v):
+    return lib().or_f64_new1(_u64(v % (1 << 64)))
+
+
+def f64_as_int(v):
+    return lib().or_f64_as_int1(_u64(v))
+
+
+def f64_mul(a, b):
+    return lib().or_f64_mul1(_u64(a), _u64(b))
+
+
+def f64_add(a, b):
+    return lib().or_f64_add1(_u64(a), _u64(b))
+
+
+def f64_sub(a, b):
+    return lib().or_f64_sub1(_u64(a), _u64(b))
+
+
+def f64_inv(a):
+    return lib().or_f64_inv1(_u64(a))
+
+
+def f64_exp(a, e):
+    return lib().or_f64_exp1(_u64(a), _u64(e))
+
+
+def f64_root_of_unity(log_n):
+    return lib().or_f64_root_of_unity1(log_n)
+
+
+def f64_ext_mul(D, a, b):
+    a, b = _u64arr(a), _u64arr(b)
+    out = np.empty(D, dtype=np.uint64)
+    lib().or_f64_ext_mul(ctypes.c_uint(D), _ptr(a), _ptr(b), _ptr(out))
+    return out
+
+
+# ---- fft ------------------------------------------------------------------------------------------
+def get_twiddles(n):
+    out = np.empty(n // 2, dtype=np.uint64)
+    lib().or_f64_get_twiddles(_ptr(out), _u64(n))
+    return out
+
+
+def get_inv_twiddles(n):
+    out = np.empty(n // 2, dtype=np.uint64)
+    lib().or_f64_get_inv_twiddles(_ptr(out), _u64(n))
+    return out
+
+
+def permute_index(size, index):
+    return lib().or_permute_index(_u64(size), _u64(index))
+
+
+def evaluate_poly(p, D=1, par=False):
+    """fft::evaluate_poly — natural-order coefficients -> natural-order evaluations (copy)."""
+    v = _u64arr(p).copy()
+    n = v.size // D
+    tw = get_twiddles(n)
+    fn = lib().or_f64_evaluate_poly_par if par else lib().or_f64_evaluate_poly
+    fn(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw))
+    return v
+
+
+def interpolate_poly(ev, D=1, par=False):
+    v = _u64arr(ev).copy()
+    n = v.size // D
+    tw = get_inv_twiddles(n)
+    fn = lib().or_f64_interpolate_poly_par if par else lib().or_f64_interpolate_poly
+    fn(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw))
+    return v
+
+
+def evaluate_poly_with_offset(p, domain_offset, blowup, D=1, par=False):
+    v = _u64arr(p)
+    n = v.size // D
+    tw = get_twiddles(n)
+    out = np.empty(n * blowup * D, dtype=np.uint64)
+    fn = lib().or_f64_evaluate_poly_with_offset_par if par else lib().or_f64_evaluate_poly_with_offset
+    fn(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw), _u64(domain_offset), _u64(blowup), _ptr(out))
+    return out
+
+
+def interpolate_poly_with_offset(ev, domain_offset, D=1):
+    v = _u64arr(ev).copy()
+    n = v.size // D
+    tw = get_inv_twiddles(n)
+    lib().or_f64_interpolate_poly_with_offset(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw), _u64(domain_offset))
+    return v
+
+
+def poly_eval(p, x):
+    v = _u64arr(p)
+    return lib().or_f64_poly_eval(_ptr(v), _u64(v.size), _u64(x))
+
+
+# ---- hashing --------------------------------------------------------------------------------------
+def blake3(data: bytes) -> bytes:
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    out = np.empty(32, dtype=np.uint8)
+    lib().or_blake3_hash(_ptr(buf), _u64(len(data)), _ptr(out))
+    return out.tobytes()
+
+
+def rp64_apply_permutation(state):
+    s = _u64arr(state).copy()
+    lib().or_rp64_apply_permutation(_ptr(s))
+    return s
+
+
+def rp64_mds(state, naive=False):
+    s = _u64arr(state).copy()
+    (lib().or_rp64_mds_naive if naive else lib().or_rp64_mds_freq)(_ptr(s))
+    return s
+
+
+def rp64_hash_bytes(data: bytes):
+    buf = np.frombuffer(bytes(data), dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    out = np.empty(4, dtype=np.uint64)
+    lib().or_rp64_hash_bytes(_ptr(buf), _u64(len(data)), _ptr(out))
+    return out
+
+
+def hash_elements(hasher, elems):
+    e = _u64arr(elems)
+    out = np.empty(32, dtype=np.uint8)
+    lib().or_hash_elements(ctypes.c_int(hasher), _ptr(e) if e.size else None, _u64(e.size), _ptr(out))
+    return out
+
+
+def merge(hasher, two):
+    t = np.ascontiguousarray(two).view(np.uint8).reshape(-1)
+    assert t.size == 64
+    out = np.empty(32, dtype=np.uint8)
+    lib().or_hash_merge(ctypes.c_int(hasher), _ptr(t), _ptr(out))
+    return out
+
+
+def merge_many(hasher, digests):
+    t = np.ascontiguousarray(digests).view(np.uint8).reshape(-1)
+    out = np.empty(32, dtype=np.uint8)
+    lib().or_hash_merge_many(ctypes.c_int(hasher), _ptr(t), _u64(t.size // 32), _ptr(out))
+    return out
+
+
+def merge_with_int(hasher, seed, value):
+    t = np.ascontiguousarray(seed).view(np.uint8).reshape(-1)
+    out = np.empty(32, dtype=np.uint8)
+    lib().or_hash_merge_with_int(ctypes.c_int(hasher), _ptr(t), _u64(value), _ptr(out))
+    return out
+
+
+def merkle_build(hasher, leaves, par=False):
+    """leaves: (n, 32) uint8.  Returns nodes (n, 32) uint8 in the reference heap layout (root at [1])."""
+    lv = np.ascontiguousarray(leaves).view(np.uint8).reshape(-1, 32)
+    nodes = np.empty_like(lv)
+    fn = lib().or_merkle_build_par if par else lib().or_merkle_build
+    rc = fn(ctypes.c_int(hasher), _ptr(lv), _u64(lv.shape[0]), _ptr(nodes))
+    if rc:
+        raise ValueError({1: "TooFewLeaves", 2: "NumberOfLeavesNotPowerOfTwo"}[rc])
+    return nodes
+
+
+# ---- matrices / trace commitment ------------------------------------------------------------------
+def row_width(base_cols):
+    return lib().or_row_width(_u64(base_cols))
+
+
+def partition_size(num_partitions, hash_rate, D, num_columns):
+    return lib().or_partition_size(_u64(num_partitions), _u64(hash_rate), ctypes.c_uint(D), _u64(num_columns))
+
+
+def interpolate_columns(cols, D=1, par=False):
+    """cols: (c, n*D) uint64, column-major.  Returns coefficient matrix of the same shape."""
+    v = _u64arr(cols).copy()
+    c, nD = v.shape
+    lib().or_interpolate_columns(_ptr(v), _u64(c), _u64(nD // D), ctypes.c_uint(D), ctypes.c_int(par))
+    return v
+
+
+def evaluate_polys_over(polys, blowup, domain_offset, D=1, par=False):
+    v = _u64arr(polys)
+    c, nD = v.shape
+    n = nD // D
+    rw = row_width(c * D)
+    out = np.empty((n * blowup, rw), dtype=np.uint64)
+    lib().or_evaluate_polys_over(_ptr(v), _u64(c), _u64(n), ctypes.c_uint(D), _u64(blowup), _u64(domain_offset),
+                                 _ptr(out), ctypes.c_int(par))
+    return out
+
+
+def hash_rows(hasher, data, elements_per_row, D=1, num_partitions=1, hash_rate=1):
+    v = _u64arr(data)
+    N, rw = v.shape
+    leaves = np.empty((N, 32), dtype=np.uint8)
+    lib().or_hash_rows(ctypes.c_int(hasher), _ptr(v), _u64(N), _u64(rw), _u64(elements_per_row), ctypes.c_uint(D),
+                       _u64(num_partitions), _u64(hash_rate), _ptr(leaves))
+    return leaves
+
+
+def build_trace_commitment(hasher, trace, blowup, domain_offset, D=1, num_partitions=1, hash_rate=1, par=False):
+    """trace: (c, n*D) uint64 column-major evaluations.  Returns (polys, lde, leaves, nodes)."""
+    polys = _u64arr(trace).copy()
+    c, nD = polys.shape
+    n = nD // D
+    N = n * blowup
+    rw = row_width(c * D)
+    lde = np.empty((N, rw), dtype=np.uint64)
+    leaves = np.empty((N, 32), dtype=np.uint8)
+    nodes = np.empty((N, 32), dtype=np.uint8)
+    rc = lib().or_build_trace_commitment(ctypes.c_int(hasher), _ptr(polys), _u64(c), _u64(n), ctypes.c_uint(D),
+                                         _u64(blowup), _u64(domain_offset), _u64(num_partitions), _u64(hash_rate),
+                                         _ptr(lde), _ptr(leaves), _ptr(nodes), ctypes.c_int(par))
+    assert rc == 0
+    return polys, lde, leaves, nodes

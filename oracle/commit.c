@@ -1,0 +1,223 @@
+/*
+ * ORACLE — TEST INFRASTRUCTURE ONLY (see f64.h header note).
+ *
+ * CPU restatement of the commitment layer for the f64 field:
+ *   crypto/src/hash/blake/mod.rs:24-66,131-151   Blake3_256<f64>: hash / merge / merge_many /
+ *       merge_with_int / hash_elements (f64 is not IS_CANONICAL => canonical little-endian bytes,
+ *       math/src/field/f64/mod.rs:127,661-665, no length prefix)
+ *   crypto/src/hash/rescue/rp64_256/mod.rs        (via rp64_256.c)
+ *   crypto/src/merkle/mod.rs:344-368              build_merkle_nodes (serial)
+ *   crypto/src/merkle/concurrent.rs:26-75         build_merkle_nodes (subtree per thread, OpenMP here)
+ *   prover/src/matrix/col_matrix.rs:192-202       interpolate_columns
+ *   prover/src/matrix/row_matrix.rs:84-135,184-271,298-343  evaluate_polys_over / from_segments /
+ *       commit_to_rows (incl. partitions) / get_evaluation_offsets
+ *   prover/src/matrix/segments.rs:96-190          Segment (8 interleaved columns, zero padded)
+ *   air/src/options.rs:428-444                    PartitionOptions::{partition_size, num_partitions}
+ *   prover/src/trace/trace_lde/default/mod.rs:245-282  build_trace_commitment
+ *
+ * Hasher ids: 0 = Blake3_256<f64>, 1 = Rp64_256.  A digest is 32 bytes in memory: raw bytes for
+ * Blake3, four Montgomery-form words for Rp64_256 (rp64_256/digest.rs:16).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "f64.h"
+
+void or_blake3_hash(const uint8_t *in, uint64_t len, uint8_t out[32]);
+void or_rp64_hash_elements(const uint64_t *elements, uint64_t n, uint64_t digest[4]);
+void or_rp64_merge(const uint64_t two[8], uint64_t digest[4]);
+void or_rp64_merge_with_int(const uint64_t seed[4], uint64_t value, uint64_t digest[4]);
+void or_f64_get_twiddles(uint64_t *out, uint64_t n);
+void or_f64_get_inv_twiddles(uint64_t *out, uint64_t n);
+void or_f64_interpolate_poly(uint64_t *ev, uint64_t n, unsigned D, const uint64_t *inv_twiddles);
+void or_f64_interpolate_poly_par(uint64_t *v, uint64_t n, unsigned D, const uint64_t *inv_twiddles);
+void or_f64_evaluate_poly_with_offset(const uint64_t *p, uint64_t n, unsigned D, const uint64_t *twiddles,
+                                      uint64_t domain_offset, uint64_t blowup, uint64_t *result);
+void or_f64_evaluate_poly_with_offset_par(const uint64_t *p, uint64_t n, unsigned D, const uint64_t *twiddles,
+                                          uint64_t domain_offset, uint64_t blowup, uint64_t *result);
+
+enum { H_BLAKE3_F64 = 0, H_RP64 = 1 };
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Hasher / ElementHasher                                                                         */
+
+/* hash_elements over `n` base-field words */
+void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t digest[32]) {
+    if (hasher == H_RP64) {
+        or_rp64_hash_elements(elems, n, (uint64_t *)digest);
+    } else {
+        /* blake/mod.rs:58-64: BlakeHasher.write_many -> as_int().to_le_bytes() per element */
+        uint64_t stackbuf[256];
+        uint64_t *buf = n <= 256 ? stackbuf : (uint64_t *)malloc(n * 8);
+        for (uint64_t i = 0; i < n; i++) buf[i] = f64_as_int(elems[i]);
+        or_blake3_hash((const uint8_t *)buf, n * 8, digest);
+        if (buf != stackbuf) free(buf);
+    }
+}
+
+/* merge — blake/mod.rs:33-35, rp64_256/mod.rs:181-192 */
+void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
+    if (hasher == H_RP64) or_rp64_merge((const uint64_t *)two, (uint64_t *)digest);
+    else or_blake3_hash(two, 64, digest);
+}
+
+/* merge_many — blake/mod.rs:37-39 (hash of concatenated bytes), rp64_256/mod.rs:194-196 */
+void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t digest[32]) {
+    if (hasher == H_RP64) or_rp64_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);
+    else or_blake3_hash(digests, 32 * k, digest);
+}
+
+/* merge_with_int — blake/mod.rs:41-46, rp64_256/mod.rs:198-219 */
+void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, uint8_t digest[32]) {
+    if (hasher == H_RP64) {
+        or_rp64_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
+    } else {
+        uint8_t data[40];
+        memcpy(data, seed, 32);
+        memcpy(data + 32, &value, 8);
+        or_blake3_hash(data, 40, digest);
+    }
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* MerkleTree                                                                                     */
+
+/* build_merkle_nodes — merkle/mod.rs:344-368.  nodes: n_leaves digests; nodes[0] = default (zeros);
+ * root at 1; children of i at 2i, 2i+1; nodes[n/2..n) are the parents of leaf pairs. */
+int or_merkle_build(int hasher, const uint8_t *leaves, uint64_t n_leaves, uint8_t *nodes) {
+    if (n_leaves < 2) return 1;                   /* MerkleTreeError::TooFewLeaves — mod.rs:117-119 */
+    if (n_leaves & (n_leaves - 1)) return 2;      /* NumberOfLeavesNotPowerOfTwo — mod.rs:120-122 */
+    uint64_t n = n_leaves / 2;
+    memset(nodes, 0, 32);
+    for (uint64_t i = 0; i < n; i++) or_hash_merge(hasher, leaves + 64 * i, nodes + 32 * (n + i));
+    for (uint64_t i = n - 1; i >= 1; i--) or_hash_merge(hasher, nodes + 64 * i, nodes + 32 * i);
+    return 0;
+}
+
+/* concurrent::build_merkle_nodes — merkle/concurrent.rs:26-75 */
+int or_merkle_build_par(int hasher, const uint8_t *leaves, uint64_t n_leaves, uint8_t *nodes) {
+    if (n_leaves < 2) return 1;
+    if (n_leaves & (n_leaves - 1)) return 2;
+    if (n_leaves <= 1024) return or_merkle_build(hasher, leaves, n_leaves, nodes); /* mod.rs:127-131 */
+    uint64_t n = n_leaves / 2;
+    memset(nodes, 0, 32);
+#pragma omp parallel for schedule(static)
+    for (uint64_t i = 0; i < n; i++) or_hash_merge(hasher, leaves + 64 * i, nodes + 32 * (n + i));
+#ifdef _OPENMP
+    uint64_t t = (uint64_t)omp_get_max_threads();
+#else
+    uint64_t t = 1;
+#endif
+    uint64_t num_subtrees = 1;
+    while (num_subtrees < t) num_subtrees <<= 1;
+    uint64_t batch_size0 = n / num_subtrees;
+#pragma omp parallel for schedule(static, 1)
+    for (uint64_t i = 0; i < num_subtrees; i++) {
+        uint64_t batch_size = batch_size0 / 2;
+        uint64_t start_idx = n / 2 + batch_size * i;
+        while (start_idx >= num_subtrees) {
+            for (uint64_t k = start_idx + batch_size; k-- > start_idx;)
+                or_hash_merge(hasher, nodes + 64 * k, nodes + 32 * k);
+            start_idx /= 2;
+            batch_size /= 2;
+        }
+    }
+    for (uint64_t i = num_subtrees - 1; i >= 1; i--) or_hash_merge(hasher, nodes + 64 * i, nodes + 32 * i);
+    return 0;
+}
+
+/* ---------------------------------------------------------------------------------------------- */
+/* Matrices                                                                                       */
+
+/* ColMatrix::interpolate_columns — col_matrix.rs:192-202.  cols: c columns, each n elements of D words,
+ * column-major (column k at cols + k*n*D).  In place.  par != 0 selects the concurrent.rs algorithms. */
+void or_interpolate_columns(uint64_t *cols, uint64_t c, uint64_t n, unsigned D, int par) {
+    uint64_t *inv_tw = (uint64_t *)malloc((n / 2) * 8);
+    or_f64_get_inv_twiddles(inv_tw, n);
+    for (uint64_t k = 0; k < c; k++) {
+        if (par && n >= 1024) or_f64_interpolate_poly_par(cols + k * n * D, n, D, inv_tw);
+        else or_f64_interpolate_poly(cols + k * n * D, n, D, inv_tw);
+    }
+    free(inv_tw);
+}
+
+/* row width of the RowMatrix produced by evaluate_polys_over::<8> — row_matrix.rs:112-124,275-285 */
+uint64_t or_row_width(uint64_t base_cols) { return 8 * ((base_cols + 7) / 8); }
+
+/* RowMatrix::evaluate_polys_over::<8> — row_matrix.rs:84-100 + segments.rs:96-158 + transpose :298-343.
+ * polys: c columns x n elements x D words, column-major.  out: (n*blowup) rows x row_width words,
+ * row-major, element (row, base_col) at out[row*row_width + base_col]; padding columns are zero
+ * (segments.rs:67-75 zero-fills, copy_polys only writes real columns).  Each base column is evaluated
+ * exactly like fft::evaluate_poly_with_offset (the Segment FFT is the same transform on 8 interleaved
+ * columns sharing twiddles; offsets[] of row_matrix.rs:238-271 equal the factors of serial.rs:42-49). */
+void or_evaluate_polys_over(const uint64_t *polys, uint64_t c, uint64_t n, unsigned D, uint64_t blowup,
+                            uint64_t domain_offset, uint64_t *out, int par) {
+    uint64_t base_cols = c * D, N = n * blowup, rw = or_row_width(base_cols);
+    uint64_t *tw = (uint64_t *)malloc((n / 2) * 8);
+    uint64_t *col = (uint64_t *)malloc(n * 8), *ev = (uint64_t *)malloc(N * 8);
+    or_f64_get_twiddles(tw, n);
+    memset(out, 0, N * rw * 8);
+    for (uint64_t bc = 0; bc < base_cols; bc++) {
+        uint64_t k = bc / D, d = bc % D; /* ColMatrix::get_base_element — col_matrix.rs:102-106 */
+        for (uint64_t j = 0; j < n; j++) col[j] = polys[(k * n + j) * D + d];
+        if (par && n >= 1024) or_f64_evaluate_poly_with_offset_par(col, n, 1, tw, domain_offset, blowup, ev);
+        else or_f64_evaluate_poly_with_offset(col, n, 1, tw, domain_offset, blowup, ev);
+        for (uint64_t r = 0; r < N; r++) out[r * rw + bc] = ev[r];
+    }
+    free(tw);
+    free(col);
+    free(ev);
+}
+
+/* PartitionOptions::partition_size / num_partitions — air/src/options.rs:428-444 (in columns of E) */
+uint64_t or_partition_size(uint64_t num_partitions, uint64_t hash_rate, unsigned D, uint64_t num_columns) {
+    if (num_partitions == 1) return num_columns;
+    uint64_t min_ps = hash_rate / D;
+    uint64_t ps = (num_columns + num_partitions - 1) / num_partitions;
+    return ps > min_ps ? ps : min_ps;
+}
+uint64_t or_num_partitions(uint64_t num_partitions, uint64_t hash_rate, unsigned D, uint64_t num_columns) {
+    uint64_t ps = or_partition_size(num_partitions, hash_rate, D, num_columns);
+    return (num_columns + ps - 1) / ps;
+}
+
+/* RowMatrix::commit_to_rows (row hashing part) — row_matrix.rs:184-228.
+ * data: N rows x row_width words; a row is its first `elements_per_row` words (= num_cols * D).
+ * leaves: N digests. */
+void or_hash_rows(int hasher, const uint64_t *data, uint64_t N, uint64_t row_width, uint64_t elements_per_row,
+                  unsigned D, uint64_t num_partitions, uint64_t hash_rate, uint8_t *leaves) {
+    uint64_t num_cols = elements_per_row / D;
+    uint64_t ps = or_partition_size(num_partitions, hash_rate, D, num_cols);
+    if (ps == num_cols) {
+#pragma omp parallel for schedule(static)
+        for (uint64_t r = 0; r < N; r++) or_hash_elements(hasher, data + r * row_width, elements_per_row, leaves + 32 * r);
+    } else {
+        uint64_t np = or_num_partitions(num_partitions, hash_rate, D, num_cols);
+#pragma omp parallel for schedule(static)
+        for (uint64_t r = 0; r < N; r++) {
+            uint8_t buf[16 * 32 * 16];
+            const uint64_t *row = data + r * row_width;
+            for (uint64_t k = 0; k < np; k++) { /* row.chunks(partition_size) */
+                uint64_t c0 = k * ps, c1 = (k + 1) * ps < num_cols ? (k + 1) * ps : num_cols;
+                or_hash_elements(hasher, row + c0 * D, (c1 - c0) * D, buf + 32 * k);
+            }
+            or_hash_merge_many(hasher, buf, np, leaves + 32 * r);
+        }
+    }
+}
+
+/* build_trace_commitment — trace_lde/default/mod.rs:245-282.
+ * trace: c columns x n x D words (column-major) IN: evaluations, OUT: polynomial coefficients.
+ * lde:   N x row_width words row-major (OUT).   leaves, nodes: N digests each (OUT). */
+int or_build_trace_commitment(int hasher, uint64_t *trace, uint64_t c, uint64_t n, unsigned D, uint64_t blowup,
+                              uint64_t domain_offset, uint64_t num_partitions, uint64_t hash_rate,
+                              uint64_t *lde, uint8_t *leaves, uint8_t *nodes, int par) {
+    uint64_t N = n * blowup, rw = or_row_width(c * D);
+    or_interpolate_columns(trace, c, n, D, par);                              /* extend_execution_trace */
+    or_evaluate_polys_over(trace, c, n, D, blowup, domain_offset, lde, par);
+    or_hash_rows(hasher, lde, N, rw, c * D, D, num_partitions, hash_rate, leaves); /* compute_execution_trace_commitment */
+    return par ? or_merkle_build_par(hasher, leaves, N, nodes) : or_merkle_build(hasher, leaves, N, nodes);
+}

@@ -1,0 +1,54 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+P = 2**64 - 2**32 + 1
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu via gpurun)")
+
+
+@pytest.fixture(scope="session")
+def golden():
+    with open(os.path.join(ROOT, "tests", "golden", "reference_vectors.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle as orc
+    orc.build()
+    return orc
+
+
+def splitmix64(seed, n):
+    """SURVEY.md section 8(d) input generator: SplitMix64(seed) -> rejection-sample < p (canonical ints)."""
+    out = np.empty(n, dtype=np.uint64)
+    x = seed & 0xFFFFFFFFFFFFFFFF
+    i = 0
+    mask = 0xFFFFFFFFFFFFFFFF
+    while i < n:
+        x = (x + 0x9E3779B97F4A7C15) & mask
+        z = x
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z = z ^ (z >> 31)
+        if z < P:
+            out[i] = z
+            i += 1
+    return out
+
+
+def rand_field(seed, n):
+    """Fast uniform canonical field elements (numpy PCG), for large inputs."""
+    rng = np.random.default_rng(seed)
+    v = rng.integers(0, P, size=n, dtype=np.uint64)
+    return v

@@ -1,0 +1,120 @@
+"""Pin the oracle's BLAKE3 / Rp64_256 / Merkle restatements."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import P, splitmix64
+
+
+def _llvm_blake3():
+    for cand in ("/usr/lib/x86_64-linux-gnu/libLLVM-15.so.1", "/opt/rocm/lib/llvm/lib/libclang-cpp.so"):
+        try:
+            l = ctypes.CDLL(cand)
+            l.llvm_blake3_hasher_init
+            return l
+        except (OSError, AttributeError):
+            continue
+    return None
+
+
+def test_blake3_golden(oracle, golden):
+    for case in golden["derived"]["blake3"]:
+        assert oracle.blake3(bytes.fromhex(case["in_hex"])).hex() == case["out_hex"]
+
+
+def test_blake3_vs_upstream_c(oracle):
+    """Independent oracle: the upstream BLAKE3 C implementation bundled in LLVM."""
+    l = _llvm_blake3()
+    if l is None:
+        pytest.skip("no LLVM-bundled BLAKE3 in this image")
+    rng = np.random.default_rng(3)
+    for ln in list(range(0, 130)) + [1023, 1024, 1025, 2047, 2048, 2049, 3072, 4095, 4096, 4097, 5000, 8192, 9000]:
+        data = rng.integers(0, 256, size=ln, dtype=np.uint8).tobytes()
+        st = ctypes.create_string_buffer(4096)
+        l.llvm_blake3_hasher_init(st)
+        l.llvm_blake3_hasher_update(st, data, ctypes.c_size_t(ln))
+        out = ctypes.create_string_buffer(32)
+        l.llvm_blake3_hasher_finalize(st, out, ctypes.c_size_t(32))
+        assert oracle.blake3(data) == out.raw, ln
+
+
+def test_blake3_hasher_surface(oracle, golden):
+    # blake/tests.rs: merge == merge_many for two digests; hash_elements serialises canonical LE bytes
+    d = golden["derived"]
+    h = oracle.hash_elements(oracle.H_BLAKE3_F64, oracle.f64_from_int([1, 2]))
+    assert h.tobytes().hex() == d["blake3_f64_hash_elements_1_2"]
+    lv = np.array(golden["reference"]["LEAVES4"], dtype=np.uint8)
+    assert np.array_equal(oracle.merge(oracle.H_BLAKE3_F64, lv[:2]), oracle.merge_many(oracle.H_BLAKE3_F64, lv[:2]))
+    seed = lv[0]
+    expect = oracle.blake3(seed.tobytes() + (123456789).to_bytes(8, "little"))
+    assert oracle.merge_with_int(oracle.H_BLAKE3_F64, seed, 123456789).tobytes() == expect
+
+
+def test_rp64_permutation_kat(oracle, golden):
+    # crypto/src/hash/rescue/rp64_256/tests.rs:70-105
+    st = oracle.f64_from_int(golden["reference"]["rp64_256_permutation_in"])
+    out = oracle.rp64_apply_permutation(st)
+    assert list(oracle.f64_to_int(out)) == golden["reference"]["rp64_256_permutation_out"]
+
+
+def test_rp64_mds_freq_equals_naive(oracle):
+    # tests.rs proptest: frequency-domain MDS == dense MDS (compare as field elements)
+    for seed in range(20):
+        st = oracle.f64_from_int(splitmix64(seed, 12))
+        a = oracle.f64_to_int(oracle.rp64_mds(st))
+        b = oracle.f64_to_int(oracle.rp64_mds(st, naive=True))
+        assert np.array_equal(a, b)
+    edge = oracle.f64_from_int([P - 1] * 12)
+    assert np.array_equal(oracle.f64_to_int(oracle.rp64_mds(edge)), oracle.f64_to_int(oracle.rp64_mds(edge, naive=True)))
+
+
+def test_rp64_sponge(oracle, golden):
+    d = golden["derived"]
+    z = np.zeros(8, dtype=np.uint64)
+    assert list(oracle.f64_to_int(oracle.merge(oracle.H_RP64, z).view(np.uint64))) == d["rp64_merge_zero"]
+    h = oracle.hash_elements(oracle.H_RP64, oracle.f64_from_int([1, 2, 3, 4])).view(np.uint64)
+    assert list(oracle.f64_to_int(h)) == d["rp64_hash_elements_1_2_3_4"]
+    h = oracle.hash_elements(oracle.H_RP64, oracle.f64_from_int(list(range(19)))).view(np.uint64)
+    assert list(oracle.f64_to_int(h)) == d["rp64_hash_elements_0_to_18"]
+    # tests.rs hash_elements_vs_merge: merge == hash_elements of the 8 elements
+    e = oracle.f64_from_int(splitmix64(5, 8))
+    assert np.array_equal(oracle.merge(oracle.H_RP64, e), oracle.hash_elements(oracle.H_RP64, e))
+    # tests.rs merge_vs_merge_many
+    assert np.array_equal(oracle.merge(oracle.H_RP64, e), oracle.merge_many(oracle.H_RP64, e))
+    # tests.rs hash_elements_vs_merge_with_int
+    seed = oracle.f64_from_int(splitmix64(6, 4))
+    for val in (7, P - 1):
+        exp = oracle.hash_elements(oracle.H_RP64, np.concatenate([seed, oracle.f64_from_int([val])]))
+        assert np.array_equal(oracle.merge_with_int(oracle.H_RP64, seed, val), exp)
+    val = P + 2
+    exp = oracle.hash_elements(oracle.H_RP64, np.concatenate([seed, oracle.f64_from_int([val % P, val // P])]))
+    assert np.array_equal(oracle.merge_with_int(oracle.H_RP64, seed, val), exp)
+
+
+def test_merkle_fixed_leaves(oracle, golden):
+    # crypto/src/merkle/tests.rs:68-86 (new_tree) with roots pinned by the independent BLAKE3
+    for name in ("LEAVES4", "LEAVES8"):
+        lv = np.array(golden["reference"][name], dtype=np.uint8)
+        nodes = oracle.merkle_build(oracle.H_BLAKE3_F64, lv)
+        assert nodes[1].tobytes().hex() == golden["derived"]["blake3_root_" + name]
+        assert not nodes[0].any()
+        n = lv.shape[0]
+        for i in range(n // 2):
+            assert nodes[n // 2 + i].tobytes() == oracle.blake3(lv[2 * i].tobytes() + lv[2 * i + 1].tobytes())
+        for i in range(1, n // 2):
+            assert nodes[i].tobytes() == oracle.blake3(nodes[2 * i].tobytes() + nodes[2 * i + 1].tobytes())
+
+
+def test_merkle_errors_and_concurrent(oracle):
+    rng = np.random.default_rng(1)
+    with pytest.raises(ValueError, match="TooFewLeaves"):
+        oracle.merkle_build(0, rng.integers(0, 256, (1, 32), dtype=np.uint8))
+    with pytest.raises(ValueError, match="NotPowerOfTwo"):
+        oracle.merkle_build(0, rng.integers(0, 256, (6, 32), dtype=np.uint8))
+    # merkle/concurrent.rs:87-95 proptest: concurrent == serial
+    for hasher, n in ((0, 4096), (1, 2048)):
+        lv = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        if hasher == 1:
+            lv = oracle.f64_from_int(splitmix64(9, n * 4)).view(np.uint8).reshape(n, 32)
+        assert np.array_equal(oracle.merkle_build(hasher, lv, par=True), oracle.merkle_build(hasher, lv))
