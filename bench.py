@@ -1,0 +1,174 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path on MI355X (contract: see the task statement).
+
+Workload (BASELINE.json configs[1]): standalone 2^24-point forward + inverse NTT over f64, data resident in HBM.
+A "step" = one fft::evaluate_poly followed by one fft::interpolate_poly of a 2^24-element vector (natural order in
+and out, in place) => 2 * 2^24 element-transforms per step.  value = element-transforms per second, whole job.
+With N GPUs every rank transforms its own vector (independent columns shard with no collective): weak scaling.
+
+Extra fields on the same JSON line:
+  roofline      HBM roofline of the NTT kernels (algorithmic bytes 2*n*8 per transform / measured kernel time)
+  cpu_baseline  the CPU oracle's restatement of the reference's `concurrent` (Rayon) algorithm, timed on this host
+  extra         trace-LDE+commit ms (the second half of BASELINE's metric) at 2^20 rows x 4 cols, blowup 8
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log-n", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fft, fields
+
+    ctx = winterfell_amd.default_context(local_rank)
+    n = 1 << args.log_n
+    rng = np.random.default_rng(0x5EED0001 + args.log_n + rank)
+    host = rng.integers(0, fields.M, n, dtype=np.uint64)     # uniform canonical Montgomery residues
+    data = ctx.to_device(host)
+    ref = data.clone()
+
+    def step():
+        fft.evaluate_poly(data)
+        fft.interpolate_poly(data)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert torch.equal(data, ref), "forward+inverse round trip is not the identity"
+
+    ms_per_step = elapsed * 1e3 / args.steps
+    value = 2.0 * n * args.steps * world / elapsed
+
+    out = {
+        "metric": "f64 NTT elements/s",
+        "value": value,
+        "unit": "elements/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u64",
+        "data": "synthetic",
+        "config": {"workload": "standalone 2^%d-point forward+inverse NTT over f64 (BASELINE configs[1]), in place, "
+                               "natural order, one vector per GPU" % args.log_n,
+                   "log_n": args.log_n, "step": "evaluate_poly + interpolate_poly", "parallelism": "dp%d" % world},
+    }
+
+    if rank == 0:
+        # ---- roofline: per-kernel durations from HIP events on the launch stream (wf_prof_*) ----
+        ctx.prof_enable(True)
+        reps = max(5, min(args.steps, 20))
+        for _ in range(reps):
+            fft.evaluate_poly(data)
+        prof = ctx.prof_collect()
+        ctx.prof_enable(False)
+        kern = {k: {"launches": c, "avg_us": ms * 1e3 / c} for k, (c, ms) in prof.items()}
+        total_ms = sum(ms for _, ms in prof.values())
+        fwd_us = total_ms * 1e3 / reps
+        alg_bytes = 2.0 * n * 8                         # read once + write once per transform
+        achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
+                kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
+            "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
+        }
+
+        if not args.no_extra:
+            # ---- trace LDE + commit (second half of BASELINE's metric): 2^20 rows x 4 cols, blowup 8 ----
+            ex = {}
+            for hname, tag in (("Blake3_256", "blake3"), ("Rp64_256", "rp64")):
+                hasher = getattr(crypto, hname)
+                tn, tc, tb = 1 << 20, 4, 8
+                tr = ctx.to_device(rng.integers(0, fields.M, (tc, tn), dtype=np.uint64))
+                cm = prover.ColMatrix(tr)
+                dom = prover.StarkDomain(tn, tb)
+                prover.build_trace_commitment(hasher, cm, dom)
+                torch.cuda.synchronize()
+                ts = []
+                for _ in range(5):
+                    t1 = time.perf_counter()
+                    prover.build_trace_commitment(hasher, cm, dom)
+                    torch.cuda.synchronize()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                ex["lde_commit_ms_2^20x4_b8_" + tag] = float(np.median(ts))
+            out["extra"] = ex
+
+        if not args.no_cpu_baseline:
+            # ---- CPU baseline: the oracle's restatement of the reference's concurrent algorithm ----
+            import oracle
+            ncores = os.cpu_count() or 1
+            cpu_log_n = min(args.log_n, 22)
+            cn = 1 << cpu_log_n
+            cp = host[:cn].copy()
+            oracle.get_twiddles(16)  # load the library
+            t1 = time.perf_counter()
+            reps_cpu = 0
+            while reps_cpu < 1 or (time.perf_counter() - t1 < 10.0 and reps_cpu < 8):
+                ev = oracle.evaluate_poly(cp, par=True)
+                cp2 = oracle.interpolate_poly(ev, par=True)
+                reps_cpu += 1
+            cpu_s = time.perf_counter() - t1
+            assert np.array_equal(cp2, cp)
+            out["cpu_baseline"] = {
+                "value": 2.0 * cn * reps_cpu / cpu_s, "unit": "elements/s", "cores": ncores, "kind": "port",
+                "sample": "%d x (evaluate_poly + interpolate_poly) at 2^%d points, OpenMP restatement of "
+                          "math/src/fft/concurrent.rs (includes twiddle generation)" % (reps_cpu, cpu_log_n),
+            }
+        print(json.dumps(out))
+
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

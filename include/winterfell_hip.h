@@ -1,0 +1,160 @@
+/*
+ * winterfell_hip.h — C ABI of libwinterfell_hip.so, the MI355X (gfx950) implementation of Winterfell's
+ * STARK proving hot path: math::fft NTTs / coset LDE and the crypto::merkle commitment layer.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no torch / C++ types.  Each entry point names
+ * the reference interface it stands behind (paths relative to the reference repository root).  The
+ * Rust-side binding a maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions:
+ *  - Every function returns an `int` status: WF_OK (0) or a WF_ERR_* code; nothing aborts.  The Rust shim maps
+ *    non-zero to panic! for fft/matrix preconditions (math/src/fft/mod.rs:90-102 assert!s) and to
+ *    Err(MerkleTreeError::..) for the vector commitment (crypto/src/merkle/mod.rs:117-122).
+ *  - Memory representation is exactly the reference's: f64 / f62 elements are u64 Montgomery residues
+ *    (math/src/field/f64/mod.rs:60), f128 elements are little-endian canonical u128; an extension element
+ *    is `ext_degree` consecutive base elements (math/src/field/extensions/quadratic.rs:30-33, cubic.rs:30-33);
+ *    Blake3 digests are 32 raw bytes (crypto/src/hash/mod.rs:85-114), Rp64_256 digests are 4 u64 Montgomery
+ *    residues (crypto/src/hash/rescue/rp64_256/digest.rs:16); Merkle `nodes` are in the reference heap
+ *    order: nodes[0] = zero digest, nodes[1] = root, children of i at 2i, 2i+1 (crypto/src/merkle/mod.rs:344-368).
+ *  - Pointers named d_* are DEVICE pointers (from wf_malloc or any HIP allocation, e.g. a torch tensor);
+ *    pointers named h_* are host pointers.  Work is enqueued on the context's stream; results are
+ *    complete after wf_ctx_sync() (functions that return host values synchronise themselves).
+ *  - A context is not re-entrant: use one context per calling thread (the reference calls these entry
+ *    points from one thread at a time, prover/src/lib.rs:282-492).
+ */
+#ifndef WINTERFELL_HIP_H
+#define WINTERFELL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct wf_ctx wf_ctx;
+
+/* ---- status codes ---------------------------------------------------------------------------------- */
+enum {
+    WF_OK = 0,
+    WF_ERR_INVALID_ARG = 1,          /* null pointer, zero size, bad enum ...                             */
+    WF_ERR_NOT_POWER_OF_TWO = 2,     /* fft/mod.rs:90 "number of coefficients must be a power of 2";
+                                        MerkleTreeError::NumberOfLeavesNotPowerOfTwo (merkle/mod.rs:120)  */
+    WF_ERR_TOO_FEW_LEAVES = 3,       /* MerkleTreeError::TooFewLeaves (merkle/mod.rs:117)                 */
+    WF_ERR_DOMAIN_TOO_LARGE = 4,     /* fft/mod.rs:96-100 "multiplicative subgroup of size .. does not exist" */
+    WF_ERR_UNSUPPORTED = 5,          /* field / hash / extension degree combination not available         */
+    WF_ERR_HIP = 6,                  /* a HIP runtime call failed; see wf_last_hip_error()                */
+    WF_ERR_NO_DEVICE = 7,
+    WF_ERR_ZERO_OFFSET = 8           /* fft/mod.rs:185 "domain offset cannot be zero"                     */
+};
+
+/* ---- enums ----------------------------------------------------------------------------------------- */
+enum { WF_FIELD_F64 = 0, WF_FIELD_F128 = 1, WF_FIELD_F62 = 2 };   /* math/src/field/{f64,f128,f62}       */
+enum { WF_HASH_BLAKE3_256 = 0, WF_HASH_RP64_256 = 1 };            /* crypto/src/hash/{blake,rescue/rp64_256} */
+
+/* ---- context / memory ------------------------------------------------------------------------------ */
+int wf_version(void);
+const char *wf_strerror(int status);
+int wf_device_count(int *h_count);
+int wf_ctx_create(int device_id, wf_ctx **out);
+int wf_ctx_destroy(wf_ctx *ctx);
+/* Use a caller-owned hipStream_t (e.g. torch's current stream) instead of the context's own stream. */
+int wf_ctx_set_stream(wf_ctx *ctx, void *hip_stream);
+int wf_ctx_get_stream(wf_ctx *ctx, void **hip_stream);
+int wf_ctx_sync(wf_ctx *ctx);
+int wf_last_hip_error(wf_ctx *ctx);
+
+/* Measurement hook (no reference counterpart; plays the role of the reference's tracing spans,
+ * prover/src/trace/trace_lde/default/mod.rs:258,277): when enabled every kernel launch is bracketed by HIP events
+ * on the context's stream; wf_prof_collect synchronises and writes "kernel_name launches total_ms" lines. */
+int wf_prof_enable(wf_ctx *ctx, int on);
+int wf_prof_collect(wf_ctx *ctx, char *h_buf, size_t buf_len);
+
+int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr);
+int wf_free(wf_ctx *ctx, void *d_ptr);
+int wf_memcpy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int wf_memcpy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronises */
+int wf_memcpy_d2d(wf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+
+/* ---- math::fft ------------------------------------------------------------------------------------- */
+/* fft::get_twiddles / get_inv_twiddles (math/src/fft/mod.rs:455-505): n/2 elements, bit-reverse permuted. */
+int wf_fft_get_twiddles(wf_ctx *ctx, int field, uint32_t log_n, int inverse, void *d_out);
+
+/* fft::evaluate_poly (math/src/fft/mod.rs:85-112): in place, natural-order coefficients -> natural-order
+ * evaluations over the domain of size n = 2^log_n.  `batch` independent polynomials laid out back to back
+ * (vector v at d_p + v * n * ext_degree elements). */
+int wf_fft_evaluate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_p, uint32_t log_n, uint32_t batch);
+
+/* fft::interpolate_poly (mod.rs:264-295): inverse of the above (includes the 1/n scaling). */
+int wf_fft_interpolate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
+                            uint32_t batch);
+
+/* fft::evaluate_poly_with_offset (mod.rs:168-211): d_result[k] = p(offset * g^k), k < n * 2^log_blowup,
+ * g = root of unity of the extended domain.  h_offset points to ONE base-field element (internal form). */
+int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_p, uint32_t log_n,
+                                     const void *h_offset, uint32_t log_blowup, void *d_result);
+
+/* fft::interpolate_poly_with_offset (mod.rs:351-386): in place. */
+int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
+                                        const void *h_offset);
+
+/* ---- prover::matrix -------------------------------------------------------------------------------- */
+/* ColMatrix::interpolate_columns (prover/src/matrix/col_matrix.rs:192-202): `num_cols` columns of n elements,
+ * column k at d_cols + k * col_stride elements (col_stride >= n*ext_degree, in base elements); in place. */
+int wf_interpolate_columns(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_cols, uint32_t num_cols,
+                           uint64_t col_stride, uint32_t log_n);
+
+/* Row width (in base elements) of the RowMatrix built by evaluate_polys_over::<8>:
+ * 8 * ceil(num_cols*ext_degree / 8)  (prover/src/matrix/row_matrix.rs:112-124, 275-285). */
+uint64_t wf_row_width(uint32_t num_cols, uint32_t ext_degree);
+
+/* RowMatrix::evaluate_polys_over::<8> (row_matrix.rs:84-100): coset LDE of all columns into the row-major
+ * matrix d_lde[(n << log_blowup)][row_width]; element (row r, base column j) at d_lde[r*row_width + j];
+ * padding columns are written as zero (segments.rs:67-75). */
+int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
+                           uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
+                           void *d_lde);
+
+/* RowMatrix::commit_to_rows, row-hash part (row_matrix.rs:184-228) with PartitionOptions
+ * (air/src/options.rs:428-444): leaf[r] = H::hash_elements(row r) or, when partitioned,
+ * H::merge_many(H::hash_elements(chunk_k)).  A row is its first elems_per_row base elements. */
+int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_rows, uint64_t num_rows,
+                 uint64_t row_width, uint32_t elems_per_row, uint32_t num_partitions, uint32_t hash_rate,
+                 void *d_leaves);
+
+/* ---- crypto::merkle -------------------------------------------------------------------------------- */
+/* MerkleTree::new / build_merkle_nodes (crypto/src/merkle/mod.rs:116-135, 344-368; concurrent.rs:26-75).
+ * d_leaves: num_leaves digests; d_nodes: num_leaves digests in heap order (nodes[0] zeroed). */
+int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint64_t num_leaves, void *d_nodes);
+
+/* Hasher::merge over `count` independent pairs (crypto/src/hash/mod.rs:31-50): out[i] = merge(in[2i], in[2i+1]). */
+int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t count, void *d_out);
+
+/* ElementHasher::hash_elements over `count` independent rows (hash/mod.rs:56-64); same layout as wf_hash_rows
+ * without partitions. */
+int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,
+                           uint64_t row_width, uint32_t elems_per_row, void *d_out);
+
+/* ---- prover::trace::trace_lde ---------------------------------------------------------------------- */
+/* build_trace_commitment (prover/src/trace/trace_lde/default/mod.rs:245-282), i.e. DefaultTraceLde::new /
+ * set_aux_trace and, with polynomial columns as input, build_constraint_commitment's LDE+commit
+ * (prover/src/constraints/commitment/default.rs:136-147):
+ *   d_trace  IN  trace columns (evaluations), OUT trace polynomials (TracePolyTable contents)
+ *   d_lde    OUT row-major LDE matrix, (n << log_blowup) x wf_row_width() base elements
+ *   d_leaves OUT row digests, d_nodes OUT Merkle nodes (heap order), h_root OUT 32-byte commitment
+ * If `skip_interpolate` is non-zero the columns are taken to be polynomials already (constraint
+ * composition columns). */
+int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_trace, uint32_t num_cols,
+                              uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
+                              uint32_t num_partitions, uint32_t hash_rate, int skip_interpolate, void *d_lde,
+                              void *d_leaves, void *d_nodes, void *h_root);
+
+/* TraceLde::query / read_*_frame_into row access (trace_lde/default/mod.rs:169-215): gather `count` rows
+ * (elems_per_row base elements each) of a row-major device matrix into a host buffer. */
+int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row, uint32_t elem_bytes,
+                  const uint64_t *h_positions, uint32_t count, void *h_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WINTERFELL_HIP_H */

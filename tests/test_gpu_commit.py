@@ -1,0 +1,210 @@
+"""GPU parity: hashing, Merkle trees and the fused trace LDE + commitment vs the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    return winterfell_amd.default_context(), crypto, prover, fields
+
+
+def _hid(crypto, hasher):
+    return 0 if hasher is crypto.Blake3_256 else 1
+
+
+def test_blake3_hash_elements_all_lengths(wf, oracle, golden):
+    ctx, crypto, _, fields = wf
+    h = crypto.Blake3_256
+    assert h.hash_elements(fields.from_ints([1, 2])).tobytes().hex() == golden["derived"]["blake3_f64_hash_elements_1_2"]
+    # 0..300 elements: crosses the 64-byte block and the 1024-byte chunk boundary (128 elements), multi-chunk tree
+    for n in list(range(0, 20)) + [63, 64, 65, 127, 128, 129, 200, 255, 256, 257, 300, 384, 385, 512, 640, 1000]:
+        e = oracle.f64_from_int(splitmix64(n + 1, n)) if n else np.zeros(0, dtype=np.uint64)
+        assert np.array_equal(h.hash_elements(e), oracle.hash_elements(oracle.H_BLAKE3_F64, e)), n
+
+
+def test_rp64_hash_elements_and_kat(wf, oracle, golden):
+    ctx, crypto, _, fields = wf
+    h = crypto.Rp64_256
+    d = golden["derived"]
+    got = h.hash_elements(fields.from_ints([1, 2, 3, 4])).view(np.uint64)
+    assert list(fields.to_ints(got)) == d["rp64_hash_elements_1_2_3_4"]
+    got = h.hash_elements(fields.from_ints(list(range(19)))).view(np.uint64)
+    assert list(fields.to_ints(got)) == d["rp64_hash_elements_0_to_18"]
+    z = np.zeros((2, 32), dtype=np.uint8)
+    assert list(fields.to_ints(h.merge(z).view(np.uint64))) == d["rp64_merge_zero"]
+    # the reference's permutation KAT (rp64_256/tests.rs:70-105) through the sponge: hash_elements of the 8 rate
+    # elements [4..11] with capacity word = 8 is merge(); reproduce the KAT state via the oracle-checked identity
+    for n in list(range(0, 26)) + [64, 65, 100]:
+        e = oracle.f64_from_int(splitmix64(500 + n, n)) if n else np.zeros(0, dtype=np.uint64)
+        assert np.array_equal(h.hash_elements(e), oracle.hash_elements(oracle.H_RP64, e)), n
+    edge = oracle.f64_from_int(np.full(16, P - 1, dtype=np.uint64))
+    assert np.array_equal(h.hash_elements(edge), oracle.hash_elements(oracle.H_RP64, edge))
+
+
+def test_merge_batches(wf, oracle):
+    ctx, crypto, _, fields = wf
+    rng = np.random.default_rng(2)
+    pairs = rng.integers(0, 256, (300, 2, 32), dtype=np.uint8)
+    got = crypto.Blake3_256.merge(pairs)
+    for i in (0, 1, 150, 299):
+        assert np.array_equal(got[i], oracle.merge(0, pairs[i]))
+    ep = oracle.f64_from_int(rand_field(3, 300 * 8)).view(np.uint8).reshape(300, 2, 32)
+    got = crypto.Rp64_256.merge(ep)
+    for i in (0, 7, 299):
+        assert np.array_equal(got[i], oracle.merge(1, ep[i]))
+    e = oracle.f64_from_int(rand_field(4, 8))
+    assert np.array_equal(crypto.Rp64_256.merge(e.view(np.uint8).reshape(2, 32)), crypto.Rp64_256.hash_elements(e))
+
+
+def test_merkle_reference_fixtures(wf, oracle, golden):
+    ctx, crypto, _, _ = wf
+    for name in ("LEAVES4", "LEAVES8"):
+        lv = np.array(golden["reference"][name], dtype=np.uint8)
+        tree = crypto.MerkleTree.new(crypto.Blake3_256, lv)
+        assert tree.root().tobytes().hex() == golden["derived"]["blake3_root_" + name]
+        assert np.array_equal(tree.nodes, oracle.merkle_build(0, lv))
+    # crypto/src/merkle/tests.rs:88-122 prove(): exact node lists
+    lv = np.array(golden["reference"]["LEAVES8"], dtype=np.uint8)
+    tree = crypto.MerkleTree.new(crypto.Blake3_256, lv)
+    h2 = lambda a, b: oracle.merge(0, np.stack([a, b]))
+    leaf, proof = tree.prove(1)
+    want = [lv[0], h2(lv[2], lv[3]), h2(h2(lv[4], lv[5]), h2(lv[6], lv[7]))]
+    assert np.array_equal(leaf, lv[1]) and all(np.array_equal(x, y) for x, y in zip(proof, want))
+    leaf, proof = tree.prove(6)
+    want = [lv[7], h2(lv[4], lv[5]), h2(h2(lv[0], lv[1]), h2(lv[2], lv[3]))]
+    assert np.array_equal(leaf, lv[6]) and all(np.array_equal(x, y) for x, y in zip(proof, want))
+    crypto.MerkleTree.verify(crypto.Blake3_256, tree.root(), 6, leaf, proof)
+    with pytest.raises(crypto.MerkleTreeError, match="InvalidProof"):
+        crypto.MerkleTree.verify(crypto.Blake3_256, tree.root(), 5, leaf, proof)
+    # tests.rs:149-186 prove_batch(): exact node lists
+    leaves, bp = tree.prove_batch([1, 2])
+    assert bp.depth == 3 and [len(x) for x in bp.nodes] == [2, 1]
+    assert np.array_equal(bp.nodes[0][0], lv[0]) and np.array_equal(bp.nodes[0][1], h2(h2(lv[4], lv[5]), h2(lv[6], lv[7])))
+    assert np.array_equal(bp.nodes[1][0], lv[3])
+    leaves, bp = tree.prove_batch([1, 6])
+    assert np.array_equal(bp.nodes[0][1], h2(lv[2], lv[3])) and np.array_equal(bp.nodes[1][1], h2(lv[4], lv[5]))
+    leaves, bp = tree.prove_batch(list(range(8)))
+    assert [len(x) for x in bp.nodes] == [0, 0, 0, 0]
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 10, 11, 14, 17])
+def test_merkle_vs_oracle(wf, oracle, log_n):
+    ctx, crypto, _, _ = wf
+    n = 1 << log_n
+    rng = np.random.default_rng(log_n)
+    lv = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+    assert np.array_equal(crypto.MerkleTree.new(crypto.Blake3_256, lv).nodes, oracle.merkle_build(0, lv, par=True)), log_n
+    if log_n <= 14:
+        lv = oracle.f64_from_int(rand_field(log_n, n * 4)).view(np.uint8).reshape(n, 32)
+        assert np.array_equal(crypto.MerkleTree.new(crypto.Rp64_256, lv).nodes, oracle.merkle_build(1, lv, par=True)), log_n
+
+
+def test_merkle_errors(wf):
+    ctx, crypto, _, _ = wf
+    with pytest.raises(crypto.MerkleTreeError, match="TooFewLeaves"):
+        crypto.MerkleTree.new(crypto.Blake3_256, np.zeros((1, 32), dtype=np.uint8))      # merkle/mod.rs:117
+    with pytest.raises(crypto.MerkleTreeError, match="NotPowerOfTwo"):
+        crypto.MerkleTree.new(crypto.Blake3_256, np.zeros((6, 32), dtype=np.uint8))      # merkle/mod.rs:120
+
+
+def test_fib_trace_lde_fixture(wf, oracle, golden):
+    """prover/src/trace/trace_lde/default/tests.rs:22-106 through DefaultTraceLde."""
+    ctx, crypto, prover, fields = wf
+    c0, c1 = golden["reference"]["fib_trace_col0"], golden["reference"]["fib_trace_col1"]
+    trace = np.stack([fields.from_ints(c0), fields.from_ints(c1)])
+    domain = prover.StarkDomain(8, 8)
+    lde, polys = prover.DefaultTraceLde.new(crypto.Blake3_256, prover.ColMatrix(trace), domain)
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(0, trace, 8, fields.new(7))
+    assert np.array_equal(polys.to_host(), o_polys)
+    assert np.array_equal(lde.main_segment_lde.to_host(), o_lde)
+    assert np.array_equal(lde.main_segment_oracles.nodes, o_nodes)
+    assert np.array_equal(lde.get_main_trace_commitment(), o_nodes[1])
+    assert lde.trace_len() == 64 and lde.blowup() == 8
+    cur, nxt = lde.read_main_trace_frame_into(60)
+    assert np.array_equal(cur, o_lde[60, :2]) and np.array_equal(nxt, o_lde[4, :2])   # wraps around
+    (rows, (leaves, proof)), = lde.query([3, 17, 40])
+    assert np.array_equal(rows, o_lde[[3, 17, 40], :2])
+    assert np.array_equal(np.stack(leaves), o_leaves[[3, 17, 40]])
+    with pytest.raises(AssertionError, match="number of rows"):
+        lde.set_aux_trace(prover.ColMatrix(np.zeros((1, 16), dtype=np.uint64)), prover.StarkDomain(16, 8))
+
+
+@pytest.mark.parametrize("hname,c,log_n,blowup,parts", [
+    ("Blake3_256", 64, 8, 8, 1),     # prover/src/matrix/tests.rs shape: 64 polys, n=256, blowup 8
+    ("Blake3_256", 4, 12, 8, 1),     # rescue-like 4 columns
+    ("Rp64_256", 2, 11, 8, 1),       # fib_small-like 2 columns + Rp64_256
+    ("Blake3_256", 20, 10, 4, 4),    # partitioned commitment
+    ("Rp64_256", 20, 9, 2, 4),
+    ("Blake3_256", 96, 9, 8, 1),     # row_matrix bench width 96 (768-byte rows)
+    ("Blake3_256", 150, 6, 2, 1),    # > 1 BLAKE3 chunk per row
+    ("Rp64_256", 3, 13, 8, 1),
+    ("Blake3_256", 9, 16, 8, 1),     # 2 column groups, 3-pass NTT on the LDE domain
+])
+def test_build_trace_commitment_vs_oracle(wf, oracle, hname, c, log_n, blowup, parts):
+    ctx, crypto, prover, fields = wf
+    hasher = getattr(crypto, hname)
+    n = 1 << log_n
+    trace = oracle.f64_from_int(rand_field(c * 1000 + log_n, n * c)).reshape(c, n)
+    po = prover.PartitionOptions(parts, 4)
+    lde, tree, polys = prover.build_trace_commitment(hasher, prover.ColMatrix(trace), prover.StarkDomain(n, blowup), po)
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(_hid(crypto, hasher), trace, blowup, fields.new(7),
+                                                                      num_partitions=parts, hash_rate=4, par=True)
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    assert np.array_equal(lde.to_host(), o_lde), "lde"
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_aux_segment_extension_field(wf, oracle, D):
+    ctx, crypto, prover, fields = wf
+    n, c, b = 1 << 9, 3, 8
+    main = oracle.f64_from_int(rand_field(1, n * 2)).reshape(2, n)
+    aux = oracle.f64_from_int(rand_field(D, n * c * D)).reshape(c, n * D)
+    domain = prover.StarkDomain(n, b)
+    lde, _ = prover.DefaultTraceLde.new(crypto.Blake3_256, prover.ColMatrix(main), domain)
+    polys, root = lde.set_aux_trace(prover.ColMatrix(aux, ext_degree=D), domain)
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(0, aux, b, fields.new(7), D=D)
+    assert np.array_equal(polys.to_host(), o_polys)
+    assert np.array_equal(lde.aux_segment_lde.to_host(), o_lde)
+    assert np.array_equal(root, o_nodes[1])
+    with pytest.raises(AssertionError, match="already been added"):
+        lde.set_aux_trace(prover.ColMatrix(aux, ext_degree=D), domain)
+
+
+def test_full_size_lde_commit_properties(wf, oracle):
+    """BASELINE config 3b shape (2^20 rows, blowup 8): size-independent properties instead of a full CPU run."""
+    ctx, crypto, prover, fields = wf
+    import torch
+    n, c, b = 1 << 20, 4, 8
+    trace = oracle.f64_from_int(rand_field(77, n * c)).reshape(c, n)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace), prover.StarkDomain(n, b))
+    N = n * b
+    # every blowup-th LDE row is... not the trace (coset); instead check rows by Horner at a few positions
+    hp = polys.to_host()
+    g = oracle.f64_root_of_unity(23)
+    pos = [0, 1, 7, 8, 12345, N // 2 + 3, N - 1]
+    rows = lde.rows(pos)
+    for r, k in zip(rows, pos):
+        x = oracle.f64_mul(fields.new(7), oracle.f64_exp(g, k))
+        for col in range(c):
+            assert r[col] == oracle.poly_eval(hp[col], x), (k, col)
+    # polys interpolate the trace: spot-check evaluations over the trace domain
+    w = oracle.f64_root_of_unity(20)
+    for i in (0, 5, n - 1):
+        for col in (0, 3):
+            assert oracle.poly_eval(hp[col], oracle.f64_exp(w, i)) == trace[col, i]
+    # leaves / nodes: spot-check against the oracle hasher, and the root path of one leaf
+    leaves, nodes = tree.leaves, tree.nodes
+    for k in pos:
+        assert np.array_equal(leaves[k], oracle.hash_elements(0, lde.rows([k])[0]))
+    leaf, proof = tree.prove(12345)
+    crypto.MerkleTree.verify(crypto.Blake3_256, tree.root(), 12345, leaf, proof)
+    assert not nodes[0].any()

@@ -1,0 +1,144 @@
+"""GPU parity: math::fft through the C ABI vs the CPU oracle (bit-exact on the internal u64 form)."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field, splitmix64
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd.math import fft, fields
+    return winterfell_amd.default_context(), fft, fields
+
+
+def test_library_is_native(wf):
+    ctx, _, _ = wf
+    import winterfell_amd._lib as L
+    assert L.load_library().wf_version() >= 100
+    assert L.LIB_PATH.endswith("winterfell_amd/libwinterfell_hip.so")
+
+
+def test_twiddles_match_reference_layout(wf, oracle):
+    ctx, fft, _ = wf
+    for n in (2, 4, 16, 1024, 1 << 13, 1 << 17):
+        assert np.array_equal(ctx.to_host(fft.get_twiddles(n)), oracle.get_twiddles(n)), n
+        assert np.array_equal(ctx.to_host(fft.get_inv_twiddles(n)), oracle.get_inv_twiddles(n)), n
+
+
+def test_golden_vectors(wf, oracle, golden):
+    ctx, fft, fields = wf
+    d = golden["derived"]
+    p = fields.from_ints(list(range(1, 9)))
+    assert list(fields.to_ints(fft.evaluate_poly(p.copy()))) == d["f64_ntt8_1_to_8"]
+    p = fields.from_ints(d["f64_ntt16_in"])
+    assert list(fields.to_ints(fft.evaluate_poly(p.copy()))) == d["f64_ntt16_out"]
+    out = fft.evaluate_poly_with_offset(fields.from_ints([1, 2, 3, 4]), None, fields.new(7), 2)
+    assert list(fields.to_ints(out)) == d["f64_lde_1234_b2_o7"]
+    out = fft.evaluate_poly_with_offset(fields.from_ints(d["f64_ntt16_in"]), None, fields.new(7), 8)
+    assert list(fields.to_ints(out)) == d["f64_lde16_b8_o7"]
+
+
+@pytest.mark.parametrize("log_n", list(range(1, 18)) + [19, 20])
+def test_evaluate_interpolate_vs_oracle(wf, oracle, log_n):
+    ctx, fft, fields = wf
+    n = 1 << log_n
+    p = oracle.f64_from_int(splitmix64(0x5EED0001 + log_n, n) if log_n <= 14 else rand_field(log_n, n))
+    want = oracle.evaluate_poly(p, par=log_n >= 12)
+    got = fft.evaluate_poly(p.copy())
+    assert np.array_equal(got, want), "evaluate_poly n=2^%d" % log_n
+    back = fft.interpolate_poly(got.copy())
+    assert np.array_equal(back, p), "interpolate_poly n=2^%d" % log_n
+    assert np.array_equal(fft.interpolate_poly(p.copy()), oracle.interpolate_poly(p, par=log_n >= 12))
+
+
+def test_edge_values(wf, oracle):
+    ctx, fft, fields = wf
+    n = 1 << 10
+    for fill in (0, 1, P - 1):
+        p = oracle.f64_from_int(np.full(n, fill, dtype=np.uint64))
+        assert np.array_equal(fft.evaluate_poly(p.copy()), oracle.evaluate_poly(p))
+    p = oracle.f64_from_int(np.array([P - 1, 0] * (n // 2), dtype=np.uint64))
+    assert np.array_equal(fft.evaluate_poly(p.copy()), oracle.evaluate_poly(p))
+
+
+@pytest.mark.parametrize("D", [2, 3])
+@pytest.mark.parametrize("log_n", [3, 8, 11, 13])
+def test_extension_fields(wf, oracle, D, log_n):
+    ctx, fft, fields = wf
+    n = 1 << log_n
+    p = oracle.f64_from_int(splitmix64(D * 100 + log_n, n * D))
+    assert np.array_equal(fft.evaluate_poly(p.copy(), ext_degree=D), oracle.evaluate_poly(p, D=D))
+    assert np.array_equal(fft.interpolate_poly(p.copy(), ext_degree=D), oracle.interpolate_poly(p, D=D))
+    off = fields.new(7)
+    assert np.array_equal(fft.evaluate_poly_with_offset(p, None, off, 4, ext_degree=D),
+                          oracle.evaluate_poly_with_offset(p, off, 4, D=D))
+    assert np.array_equal(fft.interpolate_poly_with_offset(p.copy(), None, off, ext_degree=D),
+                          oracle.interpolate_poly_with_offset(p, off, D=D))
+
+
+@pytest.mark.parametrize("log_n,blowup", [(1, 2), (4, 8), (9, 1), (10, 2), (12, 8), (16, 8), (17, 4)])
+def test_with_offset_vs_oracle(wf, oracle, log_n, blowup):
+    ctx, fft, fields = wf
+    n = 1 << log_n
+    p = oracle.f64_from_int(rand_field(log_n * 31 + blowup, n))
+    for off_int in (7, 3, P - 1):
+        off = fields.new(off_int)
+        got = fft.evaluate_poly_with_offset(p, None, off, blowup)
+        assert np.array_equal(got, oracle.evaluate_poly_with_offset(p, off, blowup, par=True)), (log_n, blowup, off_int)
+    ev = oracle.f64_from_int(rand_field(99 + log_n, n))
+    assert np.array_equal(fft.interpolate_poly_with_offset(ev.copy(), None, fields.new(7)),
+                          oracle.interpolate_poly_with_offset(ev, fields.new(7)))
+
+
+def test_batched_vectors(wf, oracle):
+    ctx, fft, fields = wf
+    n, batch = 1 << 9, 37
+    p = oracle.f64_from_int(rand_field(5, n * batch)).reshape(batch, n)
+    got = fft.evaluate_poly(p.copy(), batch=batch)
+    for v in (0, 1, 17, 36):
+        assert np.array_equal(got[v], oracle.evaluate_poly(p[v]))
+
+
+def test_error_behaviour(wf):
+    ctx, fft, fields = wf
+    with pytest.raises(AssertionError, match="power of 2"):
+        fft.evaluate_poly(np.zeros(12, dtype=np.uint64))          # fft/mod.rs:90
+    with pytest.raises(AssertionError, match="twiddles"):
+        fft.evaluate_poly(np.zeros(16, dtype=np.uint64), twiddles=np.zeros(4, dtype=np.uint64))   # mod.rs:91-96
+    with pytest.raises(AssertionError, match="offset cannot be zero"):
+        fft.evaluate_poly_with_offset(np.zeros(16, dtype=np.uint64), None, 0, 2)                  # mod.rs:185
+
+
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_full_size_properties(wf, oracle, log_n):
+    """BASELINE configs[1] sizes: round trip, linearity and spot values (Horner on the CPU oracle)."""
+    ctx, fft, fields = wf
+    import torch
+    n = 1 << log_n
+    a = oracle.f64_from_int(rand_field(1000 + log_n, n))
+    b = oracle.f64_from_int(rand_field(2000 + log_n, n))
+    da, db = ctx.to_device(a), ctx.to_device(b)
+    ea = fft.evaluate_poly(da.clone())
+    eb = fft.evaluate_poly(db.clone())
+    # round trip == identity
+    assert torch.equal(fft.interpolate_poly(ea.clone()), da)
+    # spot values against the definition: p(w^k) by Horner
+    host = ctx.to_host(ea)
+    w = oracle.f64_root_of_unity(log_n)
+    for k in (0, 1, 12345, n // 2 + 7, n - 1):
+        assert host[k] == oracle.poly_eval(a, oracle.f64_exp(w, k)), k
+    # linearity: NTT(a + b) == NTT(a) + NTT(b) (sum computed on the CPU oracle for a sample)
+    s = np.array([oracle.f64_add(int(x), int(y)) for x, y in zip(a[:4096], b[:4096])], dtype=np.uint64)
+    full_sum = a.copy()
+    # vectorised modular add on canonical Montgomery residues
+    t = a.astype(object) + b.astype(object)
+    full_sum = np.where(t >= P, t - P, t).astype(np.uint64)
+    assert np.array_equal(full_sum[:4096], s)
+    es = ctx.to_host(fft.evaluate_poly(ctx.to_device(full_sum)))
+    hb = ctx.to_host(eb)
+    idx = np.random.default_rng(1).integers(0, n, 2000)
+    for k in idx:
+        assert es[k] == oracle.f64_add(int(host[k]), int(hb[k]))

@@ -1,0 +1,52 @@
+"""CPU tests of the host-side mirror: representation helpers, PartitionOptions, Merkle openings (index logic)."""
+import numpy as np
+import pytest
+
+from conftest import P, splitmix64
+
+
+def test_field_representation_helpers(oracle):
+    from winterfell_amd.math import fields
+    vals = [int(v) for v in splitmix64(1, 50)] + [0, 1, P - 1]
+    for v in vals:
+        assert fields.new(v) == oracle.f64_new(v) and fields.as_int(fields.new(v)) == v
+    arr = np.array(vals, dtype=np.uint64)
+    assert np.array_equal(fields.from_ints(arr), oracle.f64_from_int(arr))
+    assert np.array_equal(fields.to_ints(fields.from_ints(arr)), arr)
+
+
+def test_partition_options(oracle):
+    from winterfell_amd.prover import PartitionOptions
+    for parts, rate, D, cols in ((1, 8, 1, 10), (4, 8, 1, 64), (4, 8, 1, 10), (4, 8, 2, 10), (16, 4, 3, 255), (8, 8, 1, 64)):
+        po = PartitionOptions(parts, rate)
+        assert po.partition_size(cols, D) == oracle.partition_size(parts, rate, D, cols)
+    with pytest.raises(AssertionError):
+        PartitionOptions(17, 1)          # air/src/options.rs:414
+    with pytest.raises(AssertionError):
+        PartitionOptions(0, 1)
+
+
+def test_merkle_openings_on_host_nodes(oracle, golden):
+    """prove / prove_batch are index walks over the reference heap layout (crypto/src/merkle/tests.rs:88-186);
+    run them over oracle-built nodes (no GPU needed)."""
+    from winterfell_amd.crypto import MerkleTree, MerkleTreeError, Blake3_256
+    lv = np.array(golden["reference"]["LEAVES8"], dtype=np.uint8)
+    tree = MerkleTree(Blake3_256, None, None, None)
+    tree._leaves, tree._nodes = lv, oracle.merkle_build(0, lv)
+    h2 = lambda a, b: oracle.merge(0, np.stack([a, b]))
+    leaf, proof = tree.prove(1)
+    want = [lv[0], h2(lv[2], lv[3]), h2(h2(lv[4], lv[5]), h2(lv[6], lv[7]))]
+    assert np.array_equal(leaf, lv[1]) and all(np.array_equal(x, y) for x, y in zip(proof, want))
+    leaves, bp = tree.prove_batch([1, 2])
+    assert [len(x) for x in bp.nodes] == [2, 1] and bp.depth == 3
+    assert np.array_equal(bp.nodes[0][1], h2(h2(lv[4], lv[5]), h2(lv[6], lv[7])))
+    leaves, bp = tree.prove_batch([1, 6])
+    assert np.array_equal(bp.nodes[0][0], lv[0]) and np.array_equal(bp.nodes[1][0], lv[7])
+    leaves, bp = tree.prove_batch(list(range(8)))
+    assert all(len(x) == 0 for x in bp.nodes) and np.array_equal(np.stack(leaves), lv)
+    with pytest.raises(MerkleTreeError, match="OutOfBounds"):
+        tree.prove(8)
+    with pytest.raises(MerkleTreeError, match="Duplicate"):
+        tree.prove_batch([1, 1])
+    with pytest.raises(MerkleTreeError, match="TooFewLeafIndexes"):
+        tree.prove_batch([])

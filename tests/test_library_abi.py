@@ -1,0 +1,73 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/winterfell_hip.h declares (no compute calls: there is no GPU here), and fails loudly without a device."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "winterfell_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(wf_[a-z0-9_]+)\s*\(", text)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    if not os.path.exists(os.path.join(ROOT, "winterfell_amd", "libwinterfell_hip.so")):
+        g.build()
+    return ctypes.CDLL(os.path.join(ROOT, "winterfell_amd", "libwinterfell_hip.so"))
+
+
+def test_every_declared_symbol_is_exported(lib):
+    names = _declared_symbols()
+    assert len(names) >= 25
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, "declared in include/winterfell_hip.h but not exported: %s" % missing
+
+
+def test_python_binding_covers_the_header():
+    from winterfell_amd import _lib
+    bound = set(_lib._PROTOS) | {"wf_strerror", "wf_version", "wf_row_width"}
+    assert set(_declared_symbols()) <= bound, sorted(set(_declared_symbols()) - bound)
+
+
+def test_status_strings_and_row_width(lib):
+    lib.wf_strerror.restype = ctypes.c_char_p
+    assert lib.wf_strerror(0) == b"ok"
+    assert b"power of two" in lib.wf_strerror(2)
+    lib.wf_row_width.restype = ctypes.c_uint64
+    # prover/src/matrix/row_matrix.rs:112-124: row width = 8 * number of 8-column segments
+    assert [lib.wf_row_width(c, d) for c, d in ((1, 1), (4, 1), (8, 1), (9, 1), (3, 3), (64, 1), (96, 1))] == [8, 8, 8, 16, 16, 64, 96]
+
+
+def test_fails_loudly_without_a_gpu(lib):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    ctx = ctypes.c_void_p()
+    assert lib.wf_ctx_create(0, ctypes.byref(ctx)) == 7          # WF_ERR_NO_DEVICE, no silent fallback
+    import winterfell_amd
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        winterfell_amd.default_context()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        from winterfell_amd.math import fft
+        import numpy as np
+        fft.evaluate_poly(np.zeros(8, dtype=np.uint64))
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under winterfell_amd/ or include/ may reference it."""
+    bad = []
+    for base in ("winterfell_amd", "include"):
+        for dp, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".hip", ".h", ".cuh", "Makefile")):
+                    src = open(os.path.join(dp, f), errors="ignore").read()
+                    if re.search(r"(import\s+oracle|from\s+oracle|liboracle|oracle/)", src):
+                        bad.append(os.path.join(dp, f))
+    assert not bad, bad

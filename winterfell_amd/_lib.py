@@ -1,0 +1,181 @@
+"""ctypes binding of libwinterfell_hip.so + device-buffer plumbing (torch tensors hold HBM allocations)."""
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libwinterfell_hip.so")
+
+WF_FIELD_F64, WF_FIELD_F128, WF_FIELD_F62 = 0, 1, 2
+WF_HASH_BLAKE3_256, WF_HASH_RP64_256 = 0, 1
+
+_u32, _u64, _int, _vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p
+
+# name -> argtypes, exactly the prototypes of include/winterfell_hip.h (all return int unless noted)
+_PROTOS = {
+    "wf_device_count": [ctypes.POINTER(_int)],
+    "wf_ctx_create": [_int, ctypes.POINTER(_vp)],
+    "wf_ctx_destroy": [_vp],
+    "wf_ctx_set_stream": [_vp, _vp],
+    "wf_ctx_get_stream": [_vp, ctypes.POINTER(_vp)],
+    "wf_ctx_sync": [_vp],
+    "wf_last_hip_error": [_vp],
+    "wf_prof_enable": [_vp, _int],
+    "wf_prof_collect": [_vp, ctypes.c_char_p, ctypes.c_size_t],
+    "wf_malloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
+    "wf_free": [_vp, _vp],
+    "wf_memcpy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
+    "wf_memcpy_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
+    "wf_memcpy_d2d": [_vp, _vp, _vp, ctypes.c_size_t],
+    "wf_fft_get_twiddles": [_vp, _int, _u32, _int, _vp],
+    "wf_fft_evaluate_poly": [_vp, _int, _u32, _vp, _u32, _u32],
+    "wf_fft_interpolate_poly": [_vp, _int, _u32, _vp, _u32, _u32],
+    "wf_fft_evaluate_poly_with_offset": [_vp, _int, _u32, _vp, _u32, _vp, _u32, _vp],
+    "wf_fft_interpolate_poly_with_offset": [_vp, _int, _u32, _vp, _u32, _vp],
+    "wf_interpolate_columns": [_vp, _int, _u32, _vp, _u32, _u64, _u32],
+    "wf_evaluate_polys_over": [_vp, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _vp],
+    "wf_hash_rows": [_vp, _int, _int, _u32, _vp, _u64, _u64, _u32, _u32, _u32, _vp],
+    "wf_merkle_build": [_vp, _int, _vp, _u64, _vp],
+    "wf_hash_merge_batch": [_vp, _int, _vp, _u64, _vp],
+    "wf_hash_elements_batch": [_vp, _int, _int, _vp, _u64, _u64, _u32, _vp],
+    "wf_build_trace_commitment": [_vp, _int, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _u32, _u32, _int, _vp, _vp,
+                                  _vp, _vp],
+    "wf_rows_fetch": [_vp, _vp, _u64, _u32, _u32, _vp, _u32, _vp],
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class WfError(RuntimeError):
+    """Non-zero status from the C ABI (the Rust shim would panic!/Err here)."""
+
+    def __init__(self, status, where=""):
+        self.status = status
+        msg = load_library().wf_strerror(status).decode()
+        super().__init__("%s: %s (status %d)" % (where or "winterfell_hip", msg, status))
+
+
+def load_library():
+    """Load libwinterfell_hip.so; raises if the HIP extension has not been built (no fallback)."""
+    global _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    "libwinterfell_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "or `make -C winterfell_amd/csrc` — there is no CPU fallback")
+            lib = ctypes.CDLL(LIB_PATH)
+            for name, args in _PROTOS.items():
+                fn = getattr(lib, name)
+                fn.argtypes = args
+                fn.restype = _int
+            lib.wf_strerror.argtypes = [_int]
+            lib.wf_strerror.restype = ctypes.c_char_p
+            lib.wf_version.restype = _int
+            lib.wf_row_width.argtypes = [_u32, _u32]
+            lib.wf_row_width.restype = _u64
+            _lib = lib
+    return _lib
+
+
+def _check(status, where):
+    if status != 0:
+        raise WfError(status, where)
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("winterfell_amd needs a HIP device (torch.cuda.is_available() is False); no CPU fallback")
+    return torch
+
+
+class Context:
+    """Owns a wf_ctx bound to one GPU; kernels run on torch's current stream of that device."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        torch = _torch()
+        self.device = torch.device("cuda", device)
+        h = _vp()
+        _check(self.lib.wf_ctx_create(device, ctypes.byref(h)), "wf_ctx_create")
+        self.handle = h
+        self.use_torch_stream()
+
+    def use_torch_stream(self):
+        torch = _torch()
+        s = torch.cuda.current_stream(self.device)
+        _check(self.lib.wf_ctx_set_stream(self.handle, _vp(s.cuda_stream)), "wf_ctx_set_stream")
+
+    def sync(self):
+        _check(self.lib.wf_ctx_sync(self.handle), "wf_ctx_sync")
+
+    def close(self):
+        if self.handle is not None:
+            self.lib.wf_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- buffers --------------------------------------------------------------------------------------
+    def to_device(self, arr):
+        """numpy uint64/uint8 array (or torch tensor) -> torch tensor in HBM (int64 / uint8 bit containers)."""
+        torch = _torch()
+        if isinstance(arr, torch.Tensor):
+            return arr.to(self.device).contiguous()
+        a = np.ascontiguousarray(arr)
+        if a.dtype == np.uint64:
+            a = a.view(np.int64)
+        elif a.dtype != np.uint8 and a.dtype != np.int64:
+            raise TypeError("expected uint64 / uint8 data, got %s" % a.dtype)
+        return torch.from_numpy(a).to(self.device)
+
+    def empty_u64(self, *shape):
+        return _torch().empty(shape, dtype=_torch().int64, device=self.device)
+
+    def empty_u8(self, *shape):
+        return _torch().empty(shape, dtype=_torch().uint8, device=self.device)
+
+    @staticmethod
+    def to_host(t):
+        a = t.detach().cpu().numpy()
+        return a.view(np.uint64) if a.dtype == np.int64 else a
+
+    def prof_enable(self, on=True):
+        _check(self.lib.wf_prof_enable(self.handle, int(on)), "wf_prof_enable")
+
+    def prof_collect(self):
+        """-> {kernel_name: (launches, total_ms)} measured with HIP events on the context's stream."""
+        buf = ctypes.create_string_buffer(1 << 16)
+        _check(self.lib.wf_prof_collect(self.handle, buf, len(buf)), "wf_prof_collect")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
+    def call(self, name, *args):
+        _check(getattr(self.lib, name)(self.handle, *args), name)
+
+
+def ptr(t):
+    return _vp(t.data_ptr())
+
+
+_default = {}
+
+
+def default_context(device=None):
+    torch = _torch()
+    if device is None:
+        device = torch.cuda.current_device()
+    if device not in _default:
+        _default[device] = Context(device)
+    return _default[device]

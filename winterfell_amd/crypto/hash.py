@@ -1,0 +1,67 @@
+"""Hasher / ElementHasher (crypto/src/hash/mod.rs:31-64) backed by the HIP kernels.
+
+Digests are 32-byte rows: raw bytes for Blake3_256 (ByteDigest<32>), four Montgomery-form u64 for Rp64_256
+(ElementDigest, crypto/src/hash/rescue/rp64_256/digest.rs:16).  The scalar methods below launch a one-element
+batch on the GPU — they exist so tests can be written exactly like the reference's; bulk work goes through
+RowMatrix.hash_rows / MerkleTree.
+"""
+import numpy as np
+
+from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, default_context, ptr
+from ..math import fields
+
+
+class _Hasher:
+    HASH_ID = None
+    COLLISION_RESISTANCE = 128
+
+    @classmethod
+    def merge(cls, values, ctx=None):
+        """Hasher::merge(&[Digest; 2]) — values: (2, 32) uint8 (or (k, 2, 32) for a batch) -> (32,) / (k, 32)."""
+        ctx = ctx or default_context()
+        v = np.ascontiguousarray(values).view(np.uint8)
+        batch = v.reshape(-1, 64)
+        d_in = ctx.to_device(batch)
+        d_out = ctx.empty_u8(batch.shape[0], 32)
+        ctx.call("wf_hash_merge_batch", cls.HASH_ID, ptr(d_in), batch.shape[0], ptr(d_out))
+        out = ctx.to_host(d_out)
+        return out[0] if v.size == 64 else out
+
+    @classmethod
+    def hash_elements(cls, elements, ctx=None):
+        """ElementHasher::hash_elements — elements: base-field words in internal form (extension elements
+        flattened).  A 2-D array hashes each row."""
+        ctx = ctx or default_context()
+        e = np.ascontiguousarray(elements, dtype=np.uint64)
+        rows = e.reshape(1, -1) if e.ndim == 1 else e
+        if rows.shape[1] == 0:
+            rows = np.zeros((rows.shape[0], 1), dtype=np.uint64)
+            width, take = 1, 0
+        else:
+            width, take = rows.shape[1], rows.shape[1]
+        d_in = ctx.to_device(rows)
+        d_out = ctx.empty_u8(rows.shape[0], 32)
+        ctx.call("wf_hash_elements_batch", cls.HASH_ID, WF_FIELD_F64, ptr(d_in), rows.shape[0], width, take, ptr(d_out))
+        out = ctx.to_host(d_out)
+        return out[0] if e.ndim == 1 else out
+
+
+class Blake3_256(_Hasher):
+    """crypto::hash::Blake3_256<f64::BaseElement> (crypto/src/hash/blake/mod.rs:24-66)."""
+    HASH_ID = WF_HASH_BLAKE3_256
+
+
+class Rp64_256(_Hasher):
+    """crypto::hash::Rp64_256 (crypto/src/hash/rescue/rp64_256/mod.rs:123-257)."""
+    HASH_ID = WF_HASH_RP64_256
+
+    @classmethod
+    def merge_many(cls, values, ctx=None):
+        """hash_elements over the digests' elements (rp64_256/mod.rs:194-196)."""
+        v = np.ascontiguousarray(values).view(np.uint64).reshape(-1)
+        return cls.hash_elements(v, ctx)
+
+    @staticmethod
+    def digest_as_bytes(digest):
+        """ElementDigest::as_bytes — canonical little-endian (rp64_256/digest.rs:36-45)."""
+        return fields.to_ints(np.ascontiguousarray(digest).view(np.uint64)).tobytes()

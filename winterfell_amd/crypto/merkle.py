@@ -1,0 +1,138 @@
+"""MerkleTree (crypto/src/merkle/mod.rs:91-458) with nodes built on the GPU.
+
+`nodes` uses the reference's heap layout (root at 1, children of i at 2i / 2i+1, nodes[0] = default digest,
+nodes[n/2..n) = parents of leaf pairs; mod.rs:344-368) so openings read it exactly as the reference does.
+Openings (prove / prove_batch) are index walks over that array and stay on the host, as in the reference;
+verification recomputes merges with the GPU hasher.
+"""
+import numpy as np
+
+from .._lib import WfError, default_context, ptr
+
+
+class MerkleTreeError(Exception):
+    """crypto/src/errors.rs MerkleTreeError variants, by name."""
+
+
+class BatchMerkleProof:
+    """crypto/src/merkle/proofs.rs BatchMerkleProof { nodes: Vec<Vec<Digest>>, depth }."""
+
+    def __init__(self, nodes, depth):
+        self.nodes = nodes
+        self.depth = depth
+
+
+class MerkleTree:
+    def __init__(self, hasher, leaves_dev, nodes_dev, ctx):
+        self.hasher = hasher
+        self.ctx = ctx
+        self._leaves_dev = leaves_dev
+        self._nodes_dev = nodes_dev
+        self._nodes = None
+        self._leaves = None
+
+    # ---- construction (MerkleTree::new, mod.rs:116-135) ------------------------------------------------
+    @classmethod
+    def new(cls, hasher, leaves, ctx=None):
+        ctx = ctx or default_context()
+        if isinstance(leaves, np.ndarray):
+            lv = np.ascontiguousarray(leaves).view(np.uint8).reshape(-1, 32)
+            d_leaves = ctx.to_device(lv)
+        else:
+            d_leaves = leaves
+        n = d_leaves.numel() // 32
+        d_nodes = ctx.empty_u8(max(n, 1), 32)
+        try:
+            ctx.call("wf_merkle_build", hasher.HASH_ID, ptr(d_leaves), n, ptr(d_nodes))
+        except WfError as e:
+            if e.status == 3:
+                raise MerkleTreeError("TooFewLeaves(2, %d)" % n) from None
+            if e.status == 2:
+                raise MerkleTreeError("NumberOfLeavesNotPowerOfTwo(%d)" % n) from None
+            raise
+        return cls(hasher, d_leaves, d_nodes, ctx)
+
+    # ---- accessors ----------------------------------------------------------------------------------------
+    @property
+    def nodes(self):
+        if self._nodes is None:
+            self._nodes = self.ctx.to_host(self._nodes_dev).reshape(-1, 32)
+        return self._nodes
+
+    @property
+    def leaves(self):
+        if self._leaves is None:
+            self._leaves = self.ctx.to_host(self._leaves_dev).reshape(-1, 32)
+        return self._leaves
+
+    @property
+    def nodes_device(self):
+        return self._nodes_dev
+
+    def root(self):
+        return self.nodes[1]
+
+    def depth(self):
+        return len(self.leaves).bit_length() - 1
+
+    # ---- openings (mod.rs:193-272) ------------------------------------------------------------------------
+    def prove(self, index):
+        n = len(self.leaves)
+        if index >= n:
+            raise MerkleTreeError("LeafIndexOutOfBounds(%d, %d)" % (n, index))
+        proof = [self.leaves[index ^ 1]]
+        i = (index + n) >> 1
+        while i > 1:
+            proof.append(self.nodes[i ^ 1])
+            i >>= 1
+        return self.leaves[index], proof
+
+    def prove_batch(self, indexes):
+        if len(indexes) == 0:
+            raise MerkleTreeError("TooFewLeafIndexes")
+        n = len(self.leaves)
+        index_map = {}
+        for pos, idx in enumerate(indexes):
+            if idx >= n:
+                raise MerkleTreeError("LeafIndexOutOfBounds(%d, %d)" % (n, idx))
+            index_map[idx] = pos
+        if len(index_map) != len(indexes):
+            raise MerkleTreeError("DuplicateLeafIndex")
+        pairs = sorted({i - (i & 1) for i in indexes})
+        leaves = [None] * len(index_map)
+        nodes = []
+        nxt = []
+        for p in pairs:
+            missing = []
+            for i in (p, p + 1):
+                if i in index_map:
+                    leaves[index_map[i]] = self.leaves[i]
+                else:
+                    missing.append(self.leaves[i])
+            nodes.append(missing)
+            nxt.append((p + n) >> 1)
+        for _ in range(1, self.depth()):
+            cur, nxt = nxt, []
+            i = 0
+            while i < len(cur):
+                sib = cur[i] ^ 1
+                if i + 1 < len(cur) and cur[i + 1] == sib:
+                    i += 1
+                else:
+                    nodes[i].append(self.nodes[sib])
+                nxt.append(sib >> 1)
+                i += 1
+        return leaves, BatchMerkleProof(nodes, self.depth())
+
+    # ---- verification (mod.rs:283-307) ----------------------------------------------------------------------
+    @staticmethod
+    def verify(hasher, root, index, leaf, proof, ctx=None):
+        pair = [leaf, proof[0]] if index & 1 == 0 else [proof[0], leaf]
+        v = hasher.merge(np.stack(pair), ctx)
+        index = (index + (1 << len(proof))) >> 1
+        for p in proof[1:]:
+            pair = [v, p] if index & 1 == 0 else [p, v]
+            v = hasher.merge(np.stack(pair), ctx)
+            index >>= 1
+        if not np.array_equal(v, np.asarray(root)):
+            raise MerkleTreeError("InvalidProof")

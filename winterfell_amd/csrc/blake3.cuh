@@ -1,0 +1,163 @@
+// BLAKE3 (default mode, 32-byte output) for gfx950, one hash per lane.
+//
+// Stands behind crypto::hash::Blake3_256 (crypto/src/hash/blake/mod.rs:24-66); the reference delegates the
+// arithmetic to the `blake3` crate, this is an independent implementation from the BLAKE3 specification.
+// All inputs on this path are whole 32-bit words (field elements are 8 or 16 bytes, digests 32 bytes,
+// merge_with_int appends a u64), so the message is supplied as a word source  w(i), i < nwords.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace b3 {
+
+enum : uint32_t { CHUNK_START = 1, CHUNK_END = 2, PARENT = 4, ROOT = 8 };
+
+__device__ __forceinline__ uint32_t iv(int i) {
+    constexpr uint32_t IV[8] = {0x6A09E667u, 0xBB67AE85u, 0x3C6EF372u, 0xA54FF53Au,
+                                0x510E527Fu, 0x9B05688Cu, 0x1F83D9ABu, 0x5BE0CD19u};
+    return IV[i];
+}
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int n) { return __builtin_amdgcn_alignbit(x, x, n); }
+
+#define B3_G(a, b, c, d, mx, my)  \
+    a = a + b + (mx);             \
+    d = rotr(d ^ a, 16);          \
+    c = c + d;                    \
+    b = rotr(b ^ c, 12);          \
+    a = a + b + (my);             \
+    d = rotr(d ^ a, 8);           \
+    c = c + d;                    \
+    b = rotr(b ^ c, 7);
+
+// message word schedule: round r uses m[SCHED[r][i]] (the spec's permutation applied r times)
+__host__ __device__ constexpr int sched(int r, int i) {
+    constexpr int PERM[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+    int idx = i;
+    for (int k = 0; k < r; k++) idx = PERM[idx];
+    return idx;
+}
+
+// Compression function; writes the first 8 output words (chaining value / root hash).
+__device__ __forceinline__ void compress(const uint32_t (&cv)[8], const uint32_t (&m)[16], uint32_t counter_lo,
+                                         uint32_t block_len, uint32_t flags, uint32_t (&out)[8]) {
+    uint32_t s0 = cv[0], s1 = cv[1], s2 = cv[2], s3 = cv[3], s4 = cv[4], s5 = cv[5], s6 = cv[6], s7 = cv[7];
+    uint32_t s8 = iv(0), s9 = iv(1), s10 = iv(2), s11 = iv(3);
+    uint32_t s12 = counter_lo, s13 = 0, s14 = block_len, s15 = flags;
+#define B3_ROUND(r)                                                                                   \
+    {                                                                                                 \
+        constexpr int i0 = sched(r, 0), i1 = sched(r, 1), i2 = sched(r, 2), i3 = sched(r, 3);         \
+        constexpr int i4 = sched(r, 4), i5 = sched(r, 5), i6 = sched(r, 6), i7 = sched(r, 7);         \
+        constexpr int i8 = sched(r, 8), i9 = sched(r, 9), i10 = sched(r, 10), i11 = sched(r, 11);     \
+        constexpr int i12 = sched(r, 12), i13 = sched(r, 13), i14 = sched(r, 14), i15 = sched(r, 15); \
+        B3_G(s0, s4, s8, s12, m[i0], m[i1]);                                                          \
+        B3_G(s1, s5, s9, s13, m[i2], m[i3]);                                                          \
+        B3_G(s2, s6, s10, s14, m[i4], m[i5]);                                                         \
+        B3_G(s3, s7, s11, s15, m[i6], m[i7]);                                                         \
+        B3_G(s0, s5, s10, s15, m[i8], m[i9]);                                                         \
+        B3_G(s1, s6, s11, s12, m[i10], m[i11]);                                                       \
+        B3_G(s2, s7, s8, s13, m[i12], m[i13]);                                                        \
+        B3_G(s3, s4, s9, s14, m[i14], m[i15]);                                                        \
+    }
+    B3_ROUND(0)
+    B3_ROUND(1)
+    B3_ROUND(2)
+    B3_ROUND(3)
+    B3_ROUND(4)
+    B3_ROUND(5)
+    B3_ROUND(6)
+#undef B3_ROUND
+    out[0] = s0 ^ s8;
+    out[1] = s1 ^ s9;
+    out[2] = s2 ^ s10;
+    out[3] = s3 ^ s11;
+    out[4] = s4 ^ s12;
+    out[5] = s5 ^ s13;
+    out[6] = s6 ^ s14;
+    out[7] = s7 ^ s15;
+}
+
+// Hash of two 32-byte digests (Hasher::merge, blake/mod.rs:33-35): one block, CHUNK_START|CHUNK_END|ROOT.
+__device__ __forceinline__ void merge(const uint32_t (&two)[16], uint32_t (&out)[8]) {
+    uint32_t cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = iv(i);
+    compress(cv, two, 0, 64, CHUNK_START | CHUNK_END | ROOT, out);
+}
+
+// One chunk (<= 256 words): returns either the root hash (root = true) or the chunk's chaining value.
+// W: callable uint32_t(uint32_t word_index) over the whole message; w0 = first word of this chunk.
+template <class W>
+__device__ __forceinline__ void chunk(const W &w, uint32_t w0, uint32_t nwords_chunk, uint32_t chunk_counter,
+                                      bool root, uint32_t (&out)[8]) {
+    uint32_t cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = iv(i);
+    const uint32_t nblocks = nwords_chunk == 0 ? 1 : (nwords_chunk + 15) / 16;
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint32_t m[16];
+        const uint32_t base = blk * 16;
+        const uint32_t left = nwords_chunk - base;  // words left including this block
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = ((uint32_t)i < left) ? w(w0 + base + i) : 0u;
+        const uint32_t block_len = left >= 16 ? 64u : left * 4u;
+        uint32_t flags = (blk == 0 ? CHUNK_START : 0u) | (blk + 1 == nblocks ? CHUNK_END : 0u);
+        if (root && blk + 1 == nblocks) flags |= ROOT;
+        uint32_t o[8];
+        compress(cv, m, (flags & ROOT) ? 0u : chunk_counter, block_len, flags, o);
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
+__device__ __forceinline__ void parent(const uint32_t (&l)[8], const uint32_t (&r)[8], bool root, uint32_t (&out)[8]) {
+    uint32_t cv[8], m[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        cv[i] = iv(i);
+        m[i] = l[i];
+        m[8 + i] = r[i];
+    }
+    compress(cv, m, 0, 64, PARENT | (root ? ROOT : 0u), out);
+}
+
+// General hash of nwords 32-bit words (any length; multi-chunk inputs use the spec's lazy-merge CV stack).
+template <class W>
+__device__ __forceinline__ void hash_words(const W &w, uint32_t nwords, uint32_t (&out)[8]) {
+    if (nwords <= 256) {
+        chunk(w, 0, nwords, 0, true, out);
+        return;
+    }
+    const uint32_t nchunks = (nwords + 255) / 256;
+    uint32_t stack[12][8];  // up to 2^12 chunks = 4 MiB per hash
+    int sp = 0;
+    uint32_t cv[8];
+    for (uint32_t c = 0; c + 1 < nchunks; c++) {
+        chunk(w, c * 256, 256, c, false, cv);
+        uint32_t total = c + 1;
+        while ((total & 1u) == 0) {
+            sp--;
+            uint32_t l[8], o[8];
+            for (int i = 0; i < 8; i++) l[i] = stack[sp][i];
+            parent(l, cv, false, o);
+            for (int i = 0; i < 8; i++) cv[i] = o[i];
+            total >>= 1;
+        }
+        for (int i = 0; i < 8; i++) stack[sp][i] = cv[i];
+        sp++;
+    }
+    const uint32_t last = nchunks - 1;
+    chunk(w, last * 256, nwords - last * 256, last, false, cv);
+    while (sp > 0) {
+        sp--;
+        uint32_t l[8], o[8];
+        for (int i = 0; i < 8; i++) l[i] = stack[sp][i];
+        parent(l, cv, sp == 0, o);
+        for (int i = 0; i < 8; i++) cv[i] = o[i];
+    }
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
+}  // namespace b3

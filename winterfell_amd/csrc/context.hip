@@ -1,0 +1,244 @@
+// Context, device memory helpers, scratch buffers and cached constant tables.
+#include "wf_internal.h"
+
+#include <stdio.h>
+#include <string.h>
+
+extern "C" int wf_version(void) { return 100; }
+
+extern "C" const char *wf_strerror(int status) {
+    switch (status) {
+        case WF_OK: return "ok";
+        case WF_ERR_INVALID_ARG: return "invalid argument";
+        case WF_ERR_NOT_POWER_OF_TWO: return "size must be a power of two";
+        case WF_ERR_TOO_FEW_LEAVES: return "a Merkle tree needs at least two leaves";
+        case WF_ERR_DOMAIN_TOO_LARGE: return "multiplicative subgroup of the requested size does not exist in the field";
+        case WF_ERR_UNSUPPORTED: return "unsupported field / hash / extension combination";
+        case WF_ERR_HIP: return "HIP runtime error";
+        case WF_ERR_NO_DEVICE: return "no such HIP device";
+        case WF_ERR_ZERO_OFFSET: return "domain offset cannot be zero";
+        default: return "unknown status";
+    }
+}
+
+extern "C" int wf_device_count(int *h_count) {
+    if (!h_count) return WF_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) n = 0;
+    *h_count = n;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_create(int device_id, wf_ctx **out) {
+    if (!out) return WF_ERR_INVALID_ARG;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || device_id < 0 || device_id >= n) return WF_ERR_NO_DEVICE;
+    wf_ctx *ctx = new wf_ctx();
+    ctx->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return WF_ERR_HIP;
+    }
+    ctx->own_stream = true;
+    *out = ctx;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_destroy(wf_ctx *ctx) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (void *p : ctx->owned) (void)hipFree(p);
+    for (int i = 0; i < 3; i++)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (auto &r : ctx->prof) {
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_set_stream(wf_ctx *ctx, void *hip_stream) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    if (ctx->own_stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+        ctx->own_stream = false;
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_get_stream(wf_ctx *ctx, void **hip_stream) {
+    if (!ctx || !hip_stream) return WF_ERR_INVALID_ARG;
+    *hip_stream = (void *)ctx->stream;
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_sync(wf_ctx *ctx) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    return WF_OK;
+}
+
+extern "C" int wf_last_hip_error(wf_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
+
+extern "C" int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr) {
+    if (!ctx || !d_ptr) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipSetDevice(ctx->device));
+    WF_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    return WF_OK;
+}
+
+extern "C" int wf_free(wf_ctx *ctx, void *d_ptr) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    WF_HIP(hipFree(d_ptr));
+    return WF_OK;
+}
+
+extern "C" int wf_memcpy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !h_src))) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));  // pageable host memory: make the call safe to return from
+    return WF_OK;
+}
+
+extern "C" int wf_memcpy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!h_dst || !d_src))) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    return WF_OK;
+}
+
+extern "C" int wf_memcpy_d2d(wf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes) {
+    if (!ctx || (bytes && (!d_dst || !d_src))) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return WF_OK;
+}
+
+// ---- profiling hook ---------------------------------------------------------------------------------
+extern "C" int wf_prof_enable(wf_ctx *ctx, int on) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    ctx->prof_enabled = on != 0;
+    return WF_OK;
+}
+
+// Synchronises, then writes one line per kernel name: "name count total_ms\n"; clears the records.
+extern "C" int wf_prof_collect(wf_ctx *ctx, char *h_buf, size_t buf_len) {
+    if (!ctx || !h_buf || buf_len == 0) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    std::map<std::string, std::pair<uint64_t, double>> acc;
+    for (auto &r : ctx->prof) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto &e = acc[r.name];
+            e.first++;
+            e.second += ms;
+        }
+        (void)hipEventDestroy(r.a);
+        (void)hipEventDestroy(r.b);
+    }
+    ctx->prof.clear();
+    size_t off = 0;
+    h_buf[0] = 0;
+    for (auto &kv : acc) {
+        int w = snprintf(h_buf + off, buf_len - off, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.first,
+                         kv.second.second);
+        if (w < 0 || (size_t)w >= buf_len - off) break;
+        off += (size_t)w;
+    }
+    return WF_OK;
+}
+
+// ---- scratch ---------------------------------------------------------------------------------------
+int wf_scratch(wf_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            WF_HIP(hipStreamSynchronize(ctx->stream));
+            WF_HIP(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        WF_HIP(hipMalloc(&ctx->scratch[slot], bytes));
+        ctx->scratch_bytes[slot] = bytes;
+    }
+    *out = ctx->scratch[slot];
+    return WF_OK;
+}
+
+// ---- tables ----------------------------------------------------------------------------------------
+static int upload(wf_ctx *ctx, const std::vector<uint64_t> &h, uint64_t **d) {
+    void *p;
+    WF_HIP(hipMalloc(&p, h.size() * sizeof(uint64_t)));
+    ctx->owned.push_back(p);
+    WF_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope in the caller
+    *d = (uint64_t *)p;
+    return WF_OK;
+}
+
+// series scale * base^i, i < 2^log_len, split lo (2^log_lo entries: base^i) x hi (scale * base^(i << log_lo))
+static void build_series(uint64_t base, uint64_t scale, uint32_t log_len, uint32_t log_lo, std::vector<uint64_t> &lo,
+                         std::vector<uint64_t> &hi) {
+    using namespace hostgl;
+    const uint64_t nlo = 1ull << log_lo, nhi = 1ull << (log_len - log_lo);
+    lo.resize(nlo);
+    hi.resize(nhi);
+    uint64_t cur = 1;
+    for (uint64_t i = 0; i < nlo; i++) {
+        lo[i] = to_mont(cur);
+        cur = mulmod(cur, base);
+    }
+    const uint64_t step = cur;  // base^(2^log_lo)
+    cur = scale;
+    for (uint64_t i = 0; i < nhi; i++) {
+        hi[i] = to_mont(cur);
+        cur = mulmod(cur, step);
+    }
+}
+
+int wf_get_series_table(wf_ctx *ctx, uint64_t base, uint64_t scale, uint32_t log_len, SeriesTable *out) {
+    auto key = std::make_tuple(base, scale, log_len);
+    auto it = ctx->series.find(key);
+    if (it == ctx->series.end()) {
+        SeriesTable t;
+        t.log_len = log_len;
+        t.log_lo = log_len < 12 ? log_len : 12;
+        std::vector<uint64_t> lo, hi;
+        build_series(base, scale, log_len, t.log_lo, lo, hi);
+        WF_TRY(upload(ctx, lo, &t.d_lo));
+        WF_TRY(upload(ctx, hi, &t.d_hi));
+        it = ctx->series.emplace(key, t).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
+int wf_get_omega_table(wf_ctx *ctx, uint32_t log_n, SeriesTable *out) {
+    auto it = ctx->omega.find(log_n);
+    if (it == ctx->omega.end()) {
+        SeriesTable t;
+        WF_TRY(wf_get_series_table(ctx, hostgl::root_of_unity(log_n), 1, log_n, &t));
+        it = ctx->omega.emplace(log_n, t).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
+int wf_get_w256(wf_ctx *ctx, uint64_t **out) {
+    if (!ctx->d_w256) {
+        std::vector<uint64_t> h(256);
+        const uint64_t w = hostgl::root_of_unity(8);
+        uint64_t cur = 1;
+        for (int i = 0; i < 256; i++) {
+            h[i] = hostgl::to_mont(cur);
+            cur = hostgl::mulmod(cur, w);
+        }
+        WF_TRY(upload(ctx, h, &ctx->d_w256));
+    }
+    *out = ctx->d_w256;
+    return WF_OK;
+}

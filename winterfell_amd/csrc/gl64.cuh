@@ -1,0 +1,103 @@
+// Device arithmetic for the reference's f64 field  p = 2^64 - 2^32 + 1  (math/src/field/f64/mod.rs).
+//
+// Values are the reference's internal representation: canonical Montgomery residues x*R mod p, R = 2^64,
+// always in [0, p) (f64/mod.rs:60).  Because field arithmetic is exact, any correct implementation that
+// keeps results canonical reproduces the reference's memory image bit for bit.
+//
+// gfx950 notes: there is no 64-bit integer multiplier; a 64x64->128 product is four v_mad_u64_u32.
+// Montgomery reduction for this prime is shift/add only (eprint 2022/274, the same form the reference
+// uses in mont_red_cst, f64/mod.rs:714-724) so a modmul is 4 mads + ~14 full-rate VALU ops.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace gl {
+
+typedef unsigned __int128 u128;
+
+constexpr uint64_t P = 0xffffffff00000001ull;
+constexpr uint64_t EPS = 0xffffffffull;  // 2^64 mod p = 2^32 - 1
+
+// a + b mod p for canonical a, b  (f64/mod.rs:319-324: a - (p - b))
+__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
+    uint64_t t = P - b;
+    uint64_t x = a - t;
+    uint32_t adj = 0u - (uint32_t)(a < t);
+    return x - (uint64_t)adj;
+}
+
+// a - b mod p for canonical a, b  (f64/mod.rs:339-343)
+__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
+    uint64_t x = a - b;
+    uint32_t adj = 0u - (uint32_t)(a < b);
+    return x - (uint64_t)adj;
+}
+
+__device__ __forceinline__ uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+
+// Montgomery reduction of a 128-bit value (xh:xl) < p * 2^64  ->  x / 2^64 mod p, canonical.
+__device__ __forceinline__ uint64_t mont_red(uint64_t xl, uint64_t xh) {
+    uint64_t a = xl + (xl << 32);
+    uint64_t e = a < xl;
+    uint64_t b = a - (a >> 32) - e;
+    uint64_t r = xh - b;
+    uint32_t adj = 0u - (uint32_t)(xh < b);
+    return r - (uint64_t)adj;
+}
+
+// Montgomery product: (aR)(bR)/R = abR  (f64/mod.rs:357-359)
+__device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
+    u128 x = (u128)a * (u128)b;
+    return mont_red((uint64_t)x, (uint64_t)(x >> 64));
+}
+
+__device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
+
+// canonical integer of an internal value (mont_to_int, f64/mod.rs:731-737)
+__device__ __forceinline__ uint64_t to_int(uint64_t a) { return mont_red(a, 0); }
+
+// Plain (non-Montgomery) reduction of lo + mid*2^64 + hi*2^96 with mid < 2^32, hi < 2^63:
+// 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).  Result canonical.
+__device__ __forceinline__ uint64_t reduce160(uint64_t lo, uint32_t mid, uint64_t hi) {
+    uint64_t t = lo - hi;
+    if (lo < hi) t -= EPS;  // + p (mod 2^64)
+    uint64_t m = ((uint64_t)mid << 32) - (uint64_t)mid;  // mid * (2^32 - 1)
+    uint64_t r = t + m;
+    if (r < t) r += EPS;  // wrapped past 2^64: 2^64 = EPS (cannot wrap twice)
+    if (r >= P) r -= P;
+    return r;
+}
+
+// x * 2^S mod p for a compile-time 0 < S < 96.  Multiplying a Montgomery residue by the plain integer
+// 2^S gives the Montgomery residue of x*2^S, so this is how the radix-16 butterflies apply the
+// twiddles omega_16^j = 2^(12 j)  (omega_64 = 8, f64/mod.rs:17,258-267).
+template <int S>
+__device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
+    static_assert(S > 0 && S < 96, "shift out of range");
+    uint64_t lo, hi;
+    uint32_t mid;
+    if (S < 32) {
+        lo = x << S;
+        mid = (uint32_t)(x >> (64 - S));
+        hi = 0;
+    } else if (S == 32) {
+        lo = x << 32;
+        mid = (uint32_t)(x >> 32);
+        hi = 0;
+    } else if (S < 64) {
+        lo = x << S;
+        mid = (uint32_t)(x >> (64 - S));
+        hi = x >> (96 - S);
+    } else if (S == 64) {
+        lo = 0;
+        mid = (uint32_t)x;
+        hi = x >> 32;
+    } else {
+        lo = 0;
+        mid = (uint32_t)(x << (S - 64));
+        hi = x >> (96 - S);
+    }
+    return reduce160(lo, mid, hi);
+}
+
+}  // namespace gl

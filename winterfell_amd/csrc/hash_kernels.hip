@@ -1,0 +1,320 @@
+// Row hashing (ElementHasher::hash_elements / merge_many over matrix rows) and Merkle tree construction.
+//
+// Reference behaviour reproduced here:
+//   RowMatrix::commit_to_rows          prover/src/matrix/row_matrix.rs:184-228 (+ PartitionOptions, air/src/options.rs:428-444)
+//   Blake3_256::{hash_elements,merge}  crypto/src/hash/blake/mod.rs:33-65  (f64: canonical LE bytes of as_int())
+//   Rp64_256::{hash_elements,merge}    crypto/src/hash/rescue/rp64_256/mod.rs:181-257
+//   build_merkle_nodes                 crypto/src/merkle/mod.rs:344-368, concurrent.rs:26-75
+//
+// Kernels: one row (or one row partition) per lane for leaf hashing; one workgroup per 1024-input subtree for the
+// tree (10 levels per launch, intermediate levels staged in LDS, every node written to the reference's heap layout).
+#include "blake3.cuh"
+#include "gl64.cuh"
+#include "rp64.cuh"
+#include "wf_internal.h"
+
+namespace {
+
+enum { MODE_F64_CANON = 0, MODE_RAW = 1 };
+
+struct Digest {
+    uint32_t w[8];
+};
+
+// ---- per-hasher primitives on 32-byte digests ----------------------------------------------------------------
+struct HBlake3 {
+    static const char *row_name() { return "hash_rows_blake3"; }
+    static const char *merkle_name() { return "merkle_stage_blake3"; }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) { b3::merge(in, out); }
+    // hash `nelem` 8-byte elements starting at p (stride 1); mode selects canonicalisation
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, int mode, uint32_t (&out)[8]) {
+        if (mode == MODE_F64_CANON) {
+            auto w = [&](uint32_t i) -> uint32_t {
+                const uint64_t v = gl::to_int(p[i >> 1]);
+                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+            };
+            b3::hash_words(w, nelem * 2, out);
+        } else {
+            auto w = [&](uint32_t i) -> uint32_t {
+                const uint64_t v = p[i >> 1];
+                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+            };
+            b3::hash_words(w, nelem * 2, out);
+        }
+    }
+};
+
+struct HRp64 {
+    static const char *row_name() { return "hash_rows_rp64"; }
+    static const char *merkle_name() { return "merkle_stage_rp64"; }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
+        uint64_t two[8], d[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) two[i] = (uint64_t)in[2 * i] | ((uint64_t)in[2 * i + 1] << 32);
+        rp64::merge(two, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, int mode, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto e = [&](uint32_t i) -> uint64_t { return p[i]; };
+        rp64::hash_elements(e, nelem, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
+};
+
+__device__ __forceinline__ void store_digest(void *dst, uint64_t idx, const uint32_t (&d)[8]) {
+    uint4 *q = reinterpret_cast<uint4 *>(dst) + idx * 2;
+    q[0] = make_uint4(d[0], d[1], d[2], d[3]);
+    q[1] = make_uint4(d[4], d[5], d[6], d[7]);
+}
+
+__device__ __forceinline__ void load_pair(const void *src, uint64_t pair_idx, uint32_t (&m)[16]) {
+    const uint4 *q = reinterpret_cast<const uint4 *>(src) + pair_idx * 4;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        uint4 v = q[i];
+        m[4 * i] = v.x;
+        m[4 * i + 1] = v.y;
+        m[4 * i + 2] = v.z;
+        m[4 * i + 3] = v.w;
+    }
+}
+
+// leaf[r * parts + k] = H(elements [k*part_elems, min((k+1)*part_elems, elems_per_row)) of row r)
+template <class H>
+__global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *rows, uint64_t num_rows, uint64_t row_width,
+                                                        uint32_t elems_per_row, uint32_t part_elems, uint32_t parts,
+                                                        int mode, void *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= num_rows * parts) return;
+    const uint64_t r = gid / parts;
+    const uint32_t k = (uint32_t)(gid % parts);
+    const uint32_t e0 = k * part_elems;
+    const uint32_t e1 = (e0 + part_elems < elems_per_row) ? e0 + part_elems : elems_per_row;
+    uint32_t d[8];
+    H::hash_elems(rows + r * row_width + e0, e1 - e0, mode, d);
+    store_digest(out, gid, d);
+}
+
+template <class H>
+__global__ __launch_bounds__(256) void merge_batch_kernel(const void *pairs, uint64_t count, void *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t m[16], d[8];
+    load_pair(pairs, gid, m);
+    H::merge(m, d);
+    store_digest(out, gid, d);
+}
+
+// One stage of the tree: `count` input digests (a power of two), each workgroup reduces a chunk of
+// CH = min(count, 1024) of them through log2(CH) levels.  Level d of the stage has count >> (d+1) nodes that
+// live at heap indices [count >> (d+1), count >> d) of `nodes`.
+template <class H>
+__global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void *nodes, uint64_t count, uint32_t log_ch) {
+    __shared__ uint4 bufA[512 * 2];
+    __shared__ uint4 bufB[256 * 2];
+    const uint32_t ch = 1u << log_ch;
+    const uint64_t wg = blockIdx.x;
+    const int tid = threadIdx.x;
+    // level 0: from global
+    {
+        const uint32_t cnt = ch >> 1;
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            uint32_t m[16], d[8];
+            load_pair(in, wg * cnt + i, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> 1) + wg * cnt + i, d);
+            bufA[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+            bufA[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
+    }
+    uint4 *src = bufA, *dst = bufB;
+    for (uint32_t lvl = 1; lvl < log_ch; lvl++) {
+        __syncthreads();
+        const uint32_t cnt = ch >> (lvl + 1);
+        for (uint32_t i = tid; i < cnt; i += 256) {
+            uint32_t m[16], d[8];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                uint4 v = src[4 * i + q];
+                m[4 * q] = v.x;
+                m[4 * q + 1] = v.y;
+                m[4 * q + 2] = v.z;
+                m[4 * q + 3] = v.w;
+            }
+            H::merge(m, d);
+            store_digest(nodes, (count >> (lvl + 1)) + wg * cnt + i, d);
+            dst[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+            dst[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+        }
+        uint4 *t = src;
+        src = dst;
+        dst = t;
+    }
+}
+
+__global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint32_t take_bytes, const uint64_t *pos,
+                                   uint32_t count, uint8_t *out) {
+    const uint32_t words = take_bytes / 8;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= (uint64_t)count * words) return;
+    const uint32_t r = (uint32_t)(gid / words), w = (uint32_t)(gid % words);
+    reinterpret_cast<uint64_t *>(out)[gid] = reinterpret_cast<const uint64_t *>(rows + pos[r] * row_bytes)[w];
+}
+
+template <class H>
+int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
+                     uint32_t part_elems, uint32_t parts, int mode, void *out) {
+    const uint64_t total = num_rows * parts;
+    const uint64_t blocks = (total + 255) / 256;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    wf_prof_begin(ctx, H::row_name());
+    hipLaunchKernelGGL(hash_rows_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, num_rows, row_width,
+                       elems_per_row, part_elems, parts, mode, out);
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+template <class H>
+int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *nodes) {
+    WF_HIP(hipMemsetAsync(nodes, 0, 32, ctx->stream));  // nodes[0] = Digest::default()
+    const uint8_t *in = (const uint8_t *)leaves;
+    uint64_t count = num_leaves;
+    while (count > 1) {
+        uint32_t log_ch = 0;
+        while ((1ull << log_ch) < count && log_ch < 10) log_ch++;
+        const uint64_t wgs = count >> log_ch;
+        if (wgs > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+        wf_prof_begin(ctx, H::merkle_name());
+        hipLaunchKernelGGL(merkle_stage_kernel<H>, dim3((uint32_t)wgs), dim3(256), 0, ctx->stream, (const void *)in, nodes,
+                           count, log_ch);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+        count = wgs;
+        in = (const uint8_t *)nodes + count * 32;  // this stage's top level = next stage's inputs
+    }
+    return WF_OK;
+}
+
+int check_hash(int hash) { return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256) ? WF_OK : WF_ERR_UNSUPPORTED; }
+
+}  // namespace
+
+extern "C" int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint64_t num_leaves, void *d_nodes) {
+    if (!ctx || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (num_leaves < 2) return WF_ERR_TOO_FEW_LEAVES;
+    if (num_leaves & (num_leaves - 1)) return WF_ERR_NOT_POWER_OF_TWO;
+    return hash == WF_HASH_BLAKE3_256 ? launch_merkle<HBlake3>(ctx, d_leaves, num_leaves, d_nodes)
+                                      : launch_merkle<HRp64>(ctx, d_leaves, num_leaves, d_nodes);
+}
+
+extern "C" int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t count, void *d_out) {
+    if (!ctx || !d_pairs || !d_out) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (count == 0) return WF_OK;
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    if (hash == WF_HASH_BLAKE3_256)
+        hipLaunchKernelGGL(merge_batch_kernel<HBlake3>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
+    else
+        hipLaunchKernelGGL(merge_batch_kernel<HRp64>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const void *d_rows, uint64_t num_rows,
+                          uint64_t row_width, uint32_t elems_per_row, uint32_t num_partitions, uint32_t hash_rate,
+                          void *d_leaves) {
+    if (!ctx || !d_rows || !d_leaves || num_rows == 0 || D == 0) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (field != WF_FIELD_F64) return WF_ERR_UNSUPPORTED;
+    if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
+    if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
+    const int mode = MODE_F64_CANON;
+    const uint64_t *rows = (const uint64_t *)d_rows;
+    // PartitionOptions::partition_size / num_partitions — air/src/options.rs:428-444 (in columns of E)
+    const uint32_t num_cols = elems_per_row / D;
+    uint32_t ps = num_cols;
+    if (num_partitions > 1) {
+        const uint32_t min_ps = hash_rate / D;
+        ps = (num_cols + num_partitions - 1) / num_partitions;
+        if (ps < min_ps) ps = min_ps;
+    }
+    if (ps >= num_cols) {
+        return hash == WF_HASH_BLAKE3_256
+                   ? launch_hash_rows<HBlake3>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves)
+                   : launch_hash_rows<HRp64>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves);
+    }
+    const uint32_t parts = (num_cols + ps - 1) / ps;
+    void *tmp;
+    WF_TRY(wf_scratch(ctx, 2, (size_t)num_rows * parts * 32, &tmp));
+    // partition digests, then leaf = merge_many(partition digests): Blake3 hashes the raw digest bytes
+    // (blake/mod.rs:37-39), Rp64_256 hashes the digests' 4*parts elements (rp64_256/mod.rs:194-196).
+    if (hash == WF_HASH_BLAKE3_256) {
+        WF_TRY(launch_hash_rows<HBlake3>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
+        return launch_hash_rows<HBlake3>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
+    }
+    WF_TRY(launch_hash_rows<HRp64>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
+    return launch_hash_rows<HRp64>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
+}
+
+extern "C" int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_rows, uint64_t num_rows,
+                            uint64_t row_width, uint32_t elems_per_row, uint32_t num_partitions, uint32_t hash_rate,
+                            void *d_leaves) {
+    return hash_rows_impl(ctx, hash, field, ext_degree, d_rows, num_rows, row_width, elems_per_row, num_partitions,
+                          hash_rate, d_leaves);
+}
+
+extern "C" int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,
+                                      uint64_t row_width, uint32_t elems_per_row, void *d_out) {
+    if (count == 0) return WF_OK;
+    return hash_rows_impl(ctx, hash, field, 1, d_elems, count, row_width, elems_per_row, 1, 1, d_out);
+}
+
+extern "C" int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row,
+                             uint32_t elem_bytes, const uint64_t *h_positions, uint32_t count, void *h_out) {
+    if (!ctx || !d_rows || !h_positions || !h_out || (elem_bytes != 8 && elem_bytes != 16)) return WF_ERR_INVALID_ARG;
+    if (count == 0) return WF_OK;
+    const uint64_t row_bytes = row_width * elem_bytes;
+    const uint32_t take = elems_per_row * elem_bytes;
+    void *tmp;
+    WF_TRY(wf_scratch(ctx, 2, (size_t)count * (take + 8), &tmp));
+    uint64_t *d_pos = (uint64_t *)tmp;
+    uint8_t *d_out = (uint8_t *)tmp + (size_t)count * 8;
+    WF_HIP(hipMemcpyAsync(d_pos, h_positions, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    const uint64_t total = (uint64_t)count * (take / 8);
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream,
+                       (const uint8_t *)d_rows, row_bytes, take, d_pos, count, d_out);
+    WF_HIP(hipGetLastError());
+    WF_HIP(hipMemcpyAsync(h_out, d_out, (size_t)count * take, hipMemcpyDeviceToHost, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    return WF_OK;
+}
+
+extern "C" int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_trace,
+                                         uint32_t num_cols, uint64_t col_stride, uint32_t log_n, uint32_t log_blowup,
+                                         const void *h_offset, uint32_t num_partitions, uint32_t hash_rate,
+                                         int skip_interpolate, void *d_lde, void *d_leaves, void *d_nodes, void *h_root) {
+    if (!ctx || !d_trace || !d_lde || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    // extend_execution_trace
+    if (!skip_interpolate) WF_TRY(wf_interpolate_columns(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n));
+    WF_TRY(wf_evaluate_polys_over(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde));
+    // compute_execution_trace_commitment
+    const uint64_t N = 1ull << (log_n + log_blowup);
+    const uint64_t rw = wf_row_width(num_cols, ext_degree);
+    WF_TRY(wf_hash_rows(ctx, hash, field, ext_degree, d_lde, N, rw, num_cols * ext_degree, num_partitions, hash_rate, d_leaves));
+    WF_TRY(wf_merkle_build(ctx, hash, d_leaves, N, d_nodes));
+    if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_nodes + 32, 32));
+    return WF_OK;
+}

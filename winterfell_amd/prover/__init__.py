@@ -1,0 +1,4 @@
+"""Mirror of the prover-side plug-in surface of the hot path: ColMatrix / RowMatrix (prover/src/matrix) and
+DefaultTraceLde + build_trace_commitment (prover/src/trace/trace_lde/default/mod.rs)."""
+from .matrix import ColMatrix, RowMatrix, PartitionOptions  # noqa: F401
+from .trace_lde import DefaultTraceLde, StarkDomain, build_trace_commitment  # noqa: F401

@@ -1,0 +1,112 @@
+"""ColMatrix / RowMatrix (prover/src/matrix/col_matrix.rs, row_matrix.rs) with HBM-resident data."""
+import ctypes
+
+import numpy as np
+
+from .._lib import WF_FIELD_F64, default_context, load_library, ptr
+from ..crypto.merkle import MerkleTree
+
+
+class PartitionOptions:
+    """air::PartitionOptions (air/src/options.rs:405-451)."""
+
+    def __init__(self, num_partitions=1, hash_rate=1):
+        assert 1 <= num_partitions <= 16, "number of partitions must be in [1, 16]"
+        assert 1 <= hash_rate <= 256, "hash rate must be in [1, 256]"
+        self.num_partitions = num_partitions
+        self.hash_rate = hash_rate
+
+    def partition_size(self, num_columns, ext_degree=1):
+        if self.num_partitions == 1:
+            return num_columns
+        return max(-(-num_columns // self.num_partitions), self.hash_rate // ext_degree)
+
+    def num_partitions_for(self, num_columns, ext_degree=1):
+        return -(-num_columns // self.partition_size(num_columns, ext_degree))
+
+
+class ColMatrix:
+    """Column-major matrix: `data` is a (num_cols, num_rows * ext_degree) device tensor (one contiguous column per row
+    of the tensor).  ColMatrix::new asserts: at least one column, power-of-two length (col_matrix.rs:44-62)."""
+
+    def __init__(self, columns, ext_degree=1, ctx=None):
+        self.ctx = ctx or default_context()
+        self.ext_degree = ext_degree
+        data = self.ctx.to_device(columns) if isinstance(columns, np.ndarray) else columns
+        assert data.dim() == 2 and data.shape[0] > 0, "a matrix must contain at least one column"
+        n = data.shape[1] // ext_degree
+        assert n > 1 and n & (n - 1) == 0, "number of rows in a matrix must be a power of 2 greater than 1"
+        self.data = data
+
+    def num_cols(self):
+        return self.data.shape[0]
+
+    def num_base_cols(self):
+        return self.data.shape[0] * self.ext_degree
+
+    def num_rows(self):
+        return self.data.shape[1] // self.ext_degree
+
+    def interpolate_columns(self):
+        """ColMatrix::interpolate_columns (col_matrix.rs:192-202): returns a new matrix of coefficients."""
+        out = self.data.clone()
+        log_n = self.num_rows().bit_length() - 1
+        self.ctx.call("wf_interpolate_columns", WF_FIELD_F64, self.ext_degree, ptr(out), self.num_cols(), out.shape[1], log_n)
+        return ColMatrix(out, self.ext_degree, self.ctx)
+
+    def to_host(self):
+        return self.ctx.to_host(self.data)
+
+
+class RowMatrix:
+    """Row-major matrix (prover/src/matrix/row_matrix.rs:28-41): data[row * row_width + col], row_width =
+    8 * ceil(base_cols / 8), only the first elements_per_row words of a row are meaningful."""
+
+    def __init__(self, data, row_width, elements_per_row, ext_degree, ctx):
+        self.data, self.row_width, self.elements_per_row, self.ext_degree, self.ctx = data, row_width, elements_per_row, ext_degree, ctx
+
+    @classmethod
+    def evaluate_polys_over(cls, polys: ColMatrix, blowup, domain_offset):
+        """RowMatrix::evaluate_polys_over::<8> (row_matrix.rs:84-100)."""
+        ctx = polys.ctx
+        n = polys.num_rows()
+        log_n, log_b = n.bit_length() - 1, blowup.bit_length() - 1
+        assert blowup & (blowup - 1) == 0
+        rw = load_library().wf_row_width(polys.num_cols(), polys.ext_degree)
+        out = ctx.empty_u64(n * blowup, rw)
+        off = ctypes.c_uint64(int(domain_offset))
+        ctx.call("wf_evaluate_polys_over", WF_FIELD_F64, polys.ext_degree, ptr(polys.data), polys.num_cols(), polys.data.shape[1],
+                 log_n, log_b, ctypes.cast(ctypes.byref(off), ctypes.c_void_p), ptr(out))
+        return cls(out, rw, polys.num_base_cols(), polys.ext_degree, ctx)
+
+    def num_rows(self):
+        return self.data.shape[0]
+
+    def num_cols(self):
+        return self.elements_per_row // self.ext_degree
+
+    def row(self, idx):
+        assert idx < self.num_rows()
+        return self.ctx.to_host(self.data[idx, : self.elements_per_row])
+
+    def rows(self, positions):
+        """Batch row fetch for TraceLde::query (wf_rows_fetch)."""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        out = np.empty((len(pos), self.elements_per_row), dtype=np.uint64)
+        self.ctx.call("wf_rows_fetch", ptr(self.data), self.row_width, self.elements_per_row, 8,
+                      pos.ctypes.data_as(ctypes.c_void_p), len(pos), out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
+    def hash_rows(self, hasher, partition_options=None):
+        po = partition_options or PartitionOptions()
+        leaves = self.ctx.empty_u8(self.num_rows(), 32)
+        self.ctx.call("wf_hash_rows", hasher.HASH_ID, WF_FIELD_F64, self.ext_degree, ptr(self.data), self.num_rows(), self.row_width,
+                      self.elements_per_row, po.num_partitions, min(po.hash_rate, 255), ptr(leaves))
+        return leaves
+
+    def commit_to_rows(self, hasher, partition_options=None):
+        """RowMatrix::commit_to_rows (row_matrix.rs:184-228) -> MerkleTree."""
+        return MerkleTree.new(hasher, self.hash_rows(hasher, partition_options), self.ctx)
+
+    def to_host(self):
+        return self.ctx.to_host(self.data)
