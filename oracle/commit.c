@@ -50,7 +50,7 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
         or_rp64_hash_elements(elems, n, (uint64_t *)digest);
     } else {
         /* blake/mod.rs:58-64: BlakeHasher.write_many -> as_int().to_le_bytes() per element */
-        uint64_t stackbuf[256];
+        uint64_t stackbuf[256] = {0};
         uint64_t *buf = n <= 256 ? stackbuf : (uint64_t *)malloc(n * 8);
         for (uint64_t i = 0; i < n; i++) buf[i] = f64_as_int(elems[i]);
         or_blake3_hash((const uint8_t *)buf, n * 8, digest);

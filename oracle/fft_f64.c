@@ -264,14 +264,19 @@ void or_f64_split_radix_fft(uint64_t *values, uint64_t n, unsigned D, const uint
     }
 }
 
+/* math/src/fft/mod.rs:34,104-111: the concurrent versions are only dispatched for n >= MIN_CONCURRENT_SIZE */
+#define MIN_CONCURRENT_SIZE 1024
+
 /* concurrent::evaluate_poly — concurrent.rs:18-21 */
 void or_f64_evaluate_poly_par(uint64_t *p, uint64_t n, unsigned D, const uint64_t *twiddles) {
+    if (n < MIN_CONCURRENT_SIZE) { or_f64_evaluate_poly(p, n, D, twiddles); return; }
     or_f64_split_radix_fft(p, n, D, twiddles);
     or_f64_permute_par(p, n, D);
 }
 
 /* concurrent::interpolate_poly — concurrent.rs:59-70 */
 void or_f64_interpolate_poly_par(uint64_t *v, uint64_t n, unsigned D, const uint64_t *inv_twiddles) {
+    if (n < MIN_CONCURRENT_SIZE) { or_f64_interpolate_poly(v, n, D, inv_twiddles); return; }
     or_f64_split_radix_fft(v, n, D, inv_twiddles);
     uint64_t inv_length = f64_inv(f64_new((uint32_t)n));
 #pragma omp parallel for schedule(static)
@@ -282,6 +287,7 @@ void or_f64_interpolate_poly_par(uint64_t *v, uint64_t n, unsigned D, const uint
 /* concurrent::evaluate_poly_with_offset — concurrent.rs:26-49 */
 void or_f64_evaluate_poly_with_offset_par(const uint64_t *p, uint64_t n, unsigned D, const uint64_t *twiddles,
                                           uint64_t domain_offset, uint64_t blowup, uint64_t *result) {
+    if (n < MIN_CONCURRENT_SIZE) { or_f64_evaluate_poly_with_offset(p, n, D, twiddles, domain_offset, blowup, result); return; }
     uint64_t domain_size = n * blowup;
     uint64_t g = f64_root_of_unity((unsigned)__builtin_ctzll(domain_size));
     for (uint64_t i = 0; i < blowup; i++) { /* par_chunks_mut: nested parallelism lives inside */

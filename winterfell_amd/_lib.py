@@ -1,4 +1,5 @@
 """ctypes binding of libwinterfell_hip.so + device-buffer plumbing (torch tensors hold HBM allocations)."""
+import atexit
 import ctypes
 import os
 import threading
@@ -63,6 +64,10 @@ def load_library():
     global _lib
     with _lock:
         if _lib is None:
+            # torch must be imported first: its bundled libamdhip64.so carries the soname libamdhip64.so.7, so our
+            # DT_NEEDED resolves to the runtime torch already loaded and the process has ONE HIP runtime (streams
+            # and allocations are shared with torch).  Loaded the other way round the process gets two runtimes.
+            import torch  # noqa: F401
             if not os.path.exists(LIB_PATH):
                 raise RuntimeError(
                     "libwinterfell_hip.so is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
@@ -104,6 +109,7 @@ class Context:
         _check(self.lib.wf_ctx_create(device, ctypes.byref(h)), "wf_ctx_create")
         self.handle = h
         self.use_torch_stream()
+        _live.append(self)
 
     def use_torch_stream(self):
         torch = _torch()
@@ -117,12 +123,8 @@ class Context:
         if self.handle is not None:
             self.lib.wf_ctx_destroy(self.handle)
             self.handle = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+        if self in _live:
+            _live.remove(self)
 
     # ---- buffers --------------------------------------------------------------------------------------
     def to_device(self, arr):
@@ -170,6 +172,18 @@ def ptr(t):
 
 
 _default = {}
+_live = []
+
+
+@atexit.register
+def _shutdown():
+    # destroy contexts while the HIP runtime (and torch's streams) are still alive
+    for c in list(_live):
+        try:
+            c.close()
+        except Exception:
+            pass
+    _default.clear()
 
 
 def default_context(device=None):
