@@ -96,8 +96,14 @@ __device__ __forceinline__ uint64_t series_at(const uint64_t *lo, const uint64_t
     return gl::mul(l, h);
 }
 
+#ifndef NTT_WAVES_PER_EU
+#define NTT_WAVES_ATTR
+#else
+#define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_WAVES_PER_EU, NTT_WAVES_PER_EU)))
+#endif
+
 template <int LOG_A, int LOG_B, bool LAST>
-__global__ __launch_bounds__(256) void ntt_pass(PassParams p) {
+__global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams p) {
     constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
     constexpr int T = 256 / B;          // tile columns
     constexpr int G = A / B;            // B-point DFTs per thread in step 2
