@@ -154,6 +154,20 @@ int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_deg
 int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row, uint32_t elem_bytes,
                   const uint64_t *h_positions, uint32_t count, void *h_out);
 
+/* ---- fri::FriProver (commit phase) ------------------------------------------------------------------- */
+/* FriProver::build_layer, first half (fri/src/prover/mod.rs:202-211): transpose_slice::<E, N> (utils/core/src/lib.rs:
+ * 166-183) into d_transposed (kept: it is the layer's `evaluations` used by query_layer, mod.rs:297-319), then
+ * build_layer_commitment (mod.rs:321-336): leaf_i = H::hash_elements(row i), MerkleTree over the len/N leaves.
+ * folding N in {2, 4, 8, 16}.  h_root receives the layer commitment that the caller writes into its channel. */
+int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_len,
+                        uint32_t folding, void *d_transposed, void *d_leaves, void *d_nodes, void *h_root);
+
+/* FriProver::build_layer, second half = folding::apply_drp (fri/src/folding/mod.rs:86-118) once the caller has drawn
+ * alpha from its channel: d_folded[i] = DRP of row i.  h_domain_offset: one base element, h_alpha: one E element
+ * (ext_degree words), both in internal form. */
+int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
+                     uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded);
+
 #ifdef __cplusplus
 }
 #endif

@@ -307,3 +307,80 @@ def build_trace_commitment(hasher, trace, blowup, domain_offset, D=1, num_partit
                                          _ptr(lde), _ptr(leaves), _ptr(nodes), ctypes.c_int(par))
     assert rc == 0
     return polys, lde, leaves, nodes
+
+
+# ---- FRI ------------------------------------------------------------------------------------------------
+def transpose_slice(src, N, D=1):
+    v = _u64arr(src)
+    out = np.empty_like(v)
+    lib().or_transpose_slice(_ptr(v), _u64(v.size // D), ctypes.c_uint(D), _u64(N), _ptr(out))
+    return out
+
+
+def fri_layer_commit(hasher, transposed, N, D=1):
+    v = _u64arr(transposed)
+    rows = v.size // (N * D)
+    leaves = np.empty((rows, 32), dtype=np.uint8)
+    nodes = np.empty((rows, 32), dtype=np.uint8)
+    rc = lib().or_fri_layer_commit(ctypes.c_int(hasher), _ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _ptr(leaves), _ptr(nodes))
+    assert rc == 0
+    return leaves, nodes
+
+
+def apply_drp(transposed, N, domain_offset, alpha, D=1):
+    v = _u64arr(transposed)
+    rows = v.size // (N * D)
+    a = _u64arr(alpha)
+    out = np.empty(rows * D, dtype=np.uint64)
+    lib().or_apply_drp(_ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _u64(domain_offset), _ptr(a), _ptr(out))
+    return out
+
+
+def fri_num_layers(domain_size, folding, blowup, remainder_max_degree):
+    lib().or_fri_num_layers.restype = _u64
+    return lib().or_fri_num_layers(_u64(domain_size), _u64(folding), _u64(blowup), _u64(remainder_max_degree))
+
+
+def fri_remainder(hasher, evals, domain_offset, blowup, D=1):
+    v = _u64arr(evals).copy()
+    n = v.size // D
+    rem = np.empty((n // blowup) * D, dtype=np.uint64)
+    com = np.empty(32, dtype=np.uint8)
+    lib().or_fri_remainder(ctypes.c_int(hasher), _ptr(v), _u64(n), ctypes.c_uint(D), _u64(domain_offset), _u64(blowup), _ptr(rem), _ptr(com))
+    return rem, com
+
+
+class RandomCoin:
+    """DefaultRandomCoin (crypto/src/random/default.rs) over the oracle's hashers."""
+
+    def __init__(self, hasher, seed_elems=()):
+        lib().or_coin_sizeof.restype = _u64
+        self._buf = ctypes.create_string_buffer(int(lib().or_coin_sizeof()))
+        s = _u64arr(list(seed_elems)) if len(seed_elems) else np.zeros(1, dtype=np.uint64)
+        lib().or_coin_new(self._buf, ctypes.c_int(hasher), _ptr(s), _u64(len(seed_elems)))
+
+    def reseed(self, digest):
+        d = np.ascontiguousarray(digest).view(np.uint8).reshape(-1)
+        lib().or_coin_reseed(self._buf, _ptr(d))
+
+    def draw(self, D=1):
+        out = np.empty(D, dtype=np.uint64)
+        rc = lib().or_coin_draw(self._buf, ctypes.c_uint(D), _ptr(out))
+        assert rc == 0
+        return out
+
+
+class ProverChannel:
+    """fri::DefaultProverChannel (fri/src/prover/channel.rs:60-127): coin seeded with no elements."""
+
+    def __init__(self, hasher, D=1):
+        self.coin = RandomCoin(hasher, ())
+        self.D = D
+        self.commitments = []
+
+    def commit_fri_layer(self, root):
+        self.commitments.append(np.array(root, copy=True))
+        self.coin.reseed(root)
+
+    def draw_fri_alpha(self):
+        return self.coin.draw(self.D)

@@ -1,0 +1,125 @@
+"""GPU parity: FRI commit phase (layer commitments, DRP folding, remainder) vs the CPU oracle."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, fri
+    from winterfell_amd.math import fields
+    return winterfell_amd.default_context(), crypto, fri, fields
+
+
+def _lde_of_random_poly(oracle, log_len, blowup, D, seed):
+    """fri/benches/prover.rs recipe: random poly of degree < len/blowup evaluated over the coset."""
+    n = (1 << log_len) // blowup
+    p = oracle.f64_from_int(rand_field(seed, n * D))
+    return oracle.evaluate_poly_with_offset(p, oracle.f64_new(7), blowup, D=D, par=True)
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+@pytest.mark.parametrize("N", [2, 4, 8, 16])
+def test_single_layer_vs_oracle(wf, oracle, D, N):
+    ctx, crypto, fri, fields = wf
+    from winterfell_amd._lib import ptr
+    log_len = 10
+    ev = _lde_of_random_poly(oracle, log_len, 8, D, 10 * D + N)
+    for hasher, hid in ((crypto.Blake3_256, 0), (crypto.Rp64_256, 1)):
+        rows = (1 << log_len) // N
+        d_ev = ctx.to_device(ev)
+        tr, leaves, nodes = ctx.empty_u64(rows, N * D), ctx.empty_u8(rows, 32), ctx.empty_u8(rows, 32)
+        root = np.empty(32, dtype=np.uint8)
+        ctx.call("wf_fri_layer_commit", hasher.HASH_ID, 0, D, ptr(d_ev), log_len, N, ptr(tr), ptr(leaves), ptr(nodes),
+                 root.ctypes.data_as(ctypes.c_void_p))
+        o_tr = oracle.transpose_slice(ev, N, D)
+        o_leaves, o_nodes = oracle.fri_layer_commit(hid, o_tr, N, D)
+        assert np.array_equal(ctx.to_host(tr).reshape(-1), o_tr)
+        assert np.array_equal(ctx.to_host(leaves), o_leaves) and np.array_equal(ctx.to_host(nodes), o_nodes)
+        assert np.array_equal(root, o_nodes[1])
+    alpha = oracle.f64_from_int(rand_field(99, D))
+    off = ctypes.c_uint64(fields.new(7))
+    folded = ctx.empty_u64(rows * D)
+    ctx.call("wf_fri_apply_drp", 0, D, ptr(tr), log_len, N, ctypes.cast(ctypes.byref(off), ctypes.c_void_p),
+             alpha.ctypes.data_as(ctypes.c_void_p), ptr(folded))
+    assert np.array_equal(ctx.to_host(folded), oracle.apply_drp(o_tr, N, fields.new(7), alpha, D))
+
+
+@pytest.mark.parametrize("hname,D,log_len,N,rem_deg", [
+    ("Blake3_256", 1, 12, 4, 31),     # fri/src/prover/tests.rs shape: trace 2^9.. blowup 8, folding 4
+    ("Blake3_256", 2, 12, 2, 31),
+    ("Rp64_256", 2, 11, 4, 7),
+    ("Blake3_256", 3, 13, 8, 31),
+    ("Blake3_256", 2, 16, 4, 31),     # folding 4, rem-deg 31 lands on 2^8
+    ("Rp64_256", 1, 10, 16, 3),
+])
+def test_build_layers_vs_oracle(wf, oracle, hname, D, log_len, N, rem_deg):
+    """FriProver::build_layers against the restated reference prover with DefaultProverChannel."""
+    ctx, crypto, fri, fields = wf
+    hasher = getattr(crypto, hname)
+    hid = 0 if hname == "Blake3_256" else 1
+    blowup = 8
+    ev = _lde_of_random_poly(oracle, log_len, blowup, D, log_len * 7 + N + D)
+    opts = fri.FriOptions(blowup, N, rem_deg)
+    # --- GPU prover driven by the (host-side) reference channel
+    chan = oracle.ProverChannel(hid, D)
+    prover = fri.FriProver(opts, hasher, ext_degree=D)
+    prover.build_layers(chan, ev.copy())
+    # --- oracle prover with an identical, independent channel
+    ochan = oracle.ProverChannel(hid, D)
+    cur, length = ev.copy(), 1 << log_len
+    nl = oracle.fri_num_layers(length, N, blowup, rem_deg)
+    assert nl == opts.num_fri_layers(length) == prover.num_layers()
+    for k in range(nl):
+        tr = oracle.transpose_slice(cur, N, D)
+        leaves, nodes = oracle.fri_layer_commit(hid, tr, N, D)
+        ochan.commit_fri_layer(nodes[1])
+        alpha = ochan.draw_fri_alpha()
+        cur = oracle.apply_drp(tr, N, fields.new(7), alpha, D)
+        length //= N
+        assert np.array_equal(prover.layers[k].commitment.nodes, nodes), "layer %d nodes" % k
+        assert np.array_equal(ctx.to_host(prover.layers[k].evaluations).reshape(-1), tr), "layer %d evaluations" % k
+    rem, com = oracle.fri_remainder(hid, cur, fields.new(7), blowup, D)
+    assert np.array_equal(prover.remainder_poly.reshape(-1), rem)
+    assert len(chan.commitments) == nl + 1
+    for a, b in zip(chan.commitments, ochan.commitments + [com]):
+        assert np.array_equal(a, b)
+    # degree check (prover/src/lib.rs:433 infer_degree analogue): remainder has at most rem_deg+1 coefficients
+    assert prover.remainder_poly.shape[0] == length // blowup <= rem_deg + 1
+
+
+def test_full_size_fold_properties(wf, oracle):
+    """BASELINE config 5 size (2^24 LDE domain, quadratic extension, folding 4, rem-deg 31 => 8 layers down to 2^8):
+    DRP folding == coefficient-form folding (fri/src/folding/mod.rs:46-85 doctest, iterated over all layers), checked
+    through the remainder polynomial, with the alphas replayed from the layer roots."""
+    ctx, crypto, fri, fields = wf
+    from winterfell_amd.math import fft
+    D, N, blowup, log_len = 2, 4, 8, 24
+    n = (1 << log_len) // blowup
+    p = oracle.f64_from_int(rand_field(5, n * D))
+    ev = fft.evaluate_poly_with_offset(ctx.to_device(p), None, fields.new(7), blowup, ext_degree=D)
+    opts = fri.FriOptions(blowup, N, 31)
+    chan = oracle.ProverChannel(0, D)
+    prover = fri.FriProver(opts, crypto.Blake3_256, ext_degree=D)
+    prover.build_layers(chan, ev)
+    assert prover.num_layers() == 8 and prover.remainder_poly.shape == (32, D)
+    # replay on canonical integers: f'(x) = sum_j alpha^j * f_j(x), f_j = coefficients j mod N; x^2 = x - 2 in the extension
+    ochan = oracle.ProverChannel(0, D)
+    c = fields.to_ints(p).reshape(n, D).astype(object)
+    for k in range(8):
+        ochan.commit_fri_layer(prover.layers[k].commitment.root())
+        a0, a1 = (int(v) for v in fields.to_ints(ochan.draw_fri_alpha()))
+        acc0, acc1 = c[N - 1::N, 0], c[N - 1::N, 1]
+        for j in reversed(range(N - 1)):
+            t0 = (acc0 * a0 - 2 * acc1 * a1) % P
+            t1 = (acc0 * a1 + acc1 * a0 + acc1 * a1) % P
+            acc0, acc1 = (t0 + c[j::N, 0]) % P, (t1 + c[j::N, 1]) % P
+        c = np.stack([acc0, acc1], axis=1)
+    want = fields.from_ints(c[::-1].astype(np.uint64))
+    assert np.array_equal(prover.remainder_poly, want)

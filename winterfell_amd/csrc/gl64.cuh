@@ -100,4 +100,31 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
     return reduce160(lo, mid, hi);
 }
 
+// ---- extension fields (math/src/field/f64/mod.rs:401-499), elements are D consecutive base words ----------
+// quadratic extension x^2 - x + 2: 3 base multiplications
+__device__ __forceinline__ void ext2_mul(const uint64_t (&a)[2], const uint64_t (&b)[2], uint64_t (&o)[2]) {
+    const uint64_t a0b0 = mul(a[0], b[0]);
+    const uint64_t a1b1 = mul(a[1], b[1]);
+    const uint64_t t = mul(add(a[0], a[1]), add(b[0], b[1]));
+    o[0] = sub(a0b0, add(a1b1, a1b1));
+    o[1] = sub(t, a0b0);
+}
+// cubic extension x^3 - x - 1: 6 base multiplications
+__device__ __forceinline__ void ext3_mul(const uint64_t (&a)[3], const uint64_t (&b)[3], uint64_t (&o)[3]) {
+    const uint64_t a0b0 = mul(a[0], b[0]), a1b1 = mul(a[1], b[1]), a2b2 = mul(a[2], b[2]);
+    const uint64_t s01 = mul(add(a[0], a[1]), add(b[0], b[1]));
+    const uint64_t s02 = mul(add(a[0], a[2]), add(b[0], b[2]));
+    const uint64_t s12 = mul(add(a[1], a[2]), add(b[1], b[2]));
+    const uint64_t m = sub(a0b0, a1b1);
+    o[0] = sub(add(s12, m), a2b2);
+    o[1] = sub(sub(add(s01, s12), add(a1b1, a1b1)), a0b0);
+    o[2] = sub(s02, m);
+}
+template <int D>
+__device__ __forceinline__ void ext_mul(const uint64_t (&a)[D], const uint64_t (&b)[D], uint64_t (&o)[D]) {
+    if constexpr (D == 1) o[0] = mul(a[0], b[0]);
+    else if constexpr (D == 2) ext2_mul(a, b, o);
+    else ext3_mul(a, b, o);
+}
+
 }  // namespace gl
