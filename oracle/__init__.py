@@ -384,3 +384,144 @@ class ProverChannel:
 
     def draw_fri_alpha(self):
         return self.coin.draw(self.D)
+
+
+# ---- field-generic template instantiations (field_tmpl.inc): f128 and the f64 cross-check copy -----------
+class GenericField:
+    """Elements are W little-endian u64 words (W = 2 for f128).  Arrays are uint64 with the word axis last/flattened."""
+
+    def __init__(self, name, words, modulus):
+        self.name, self.W, self.M = name, words, modulus
+
+    def _fn(self, n):
+        return getattr(lib(), "or_%s_%s" % (self.name, n))
+
+    # scalars as python ints <-> W-word arrays (internal representation: canonical for f128, Montgomery for f64t)
+    def pack(self, vals):
+        vals = np.asarray(vals, dtype=object).reshape(-1)
+        out = np.empty((len(vals), self.W), dtype=np.uint64)
+        for k in range(self.W):
+            out[:, k] = [(int(v) >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for v in vals]
+        return out.reshape(-1)
+
+    def unpack(self, arr):
+        a = _u64arr(arr).reshape(-1, self.W)
+        return [sum(int(a[i, k]) << (64 * k) for k in range(self.W)) for i in range(a.shape[0])]
+
+    def _bin(self, name, a, b):
+        out = np.empty(self.W, dtype=np.uint64)
+        pa, pb = self.pack([a]), self.pack([b])      # keep the temporaries alive across the call
+        self._fn(name)(_ptr(pa), _ptr(pb), _ptr(out))
+        return self.unpack(out)[0]
+
+    def mul(self, a, b):
+        return self._bin("mul", a, b)
+
+    def add(self, a, b):
+        return self._bin("add", a, b)
+
+    def sub(self, a, b):
+        return self._bin("sub", a, b)
+
+    def inv(self, a):
+        out = np.empty(self.W, dtype=np.uint64)
+        pa = self.pack([a])
+        self._fn("inv")(_ptr(pa), _ptr(out))
+        return self.unpack(out)[0]
+
+    def exp(self, a, e):
+        out = np.empty(self.W, dtype=np.uint64)
+        pa = self.pack([a])
+        self._fn("exp")(_ptr(pa), _u64(e), _ptr(out))
+        return self.unpack(out)[0]
+
+    def root_of_unity(self, log_n):
+        out = np.empty(self.W, dtype=np.uint64)
+        self._fn("root_of_unity")(ctypes.c_uint(log_n), _ptr(out))
+        return self.unpack(out)[0]
+
+    def ext_mul(self, D, a, b):
+        out = np.empty(D * self.W, dtype=np.uint64)
+        pa, pb = self.pack(a), self.pack(b)
+        self._fn("ext_mul")(ctypes.c_uint(D), _ptr(pa), _ptr(pb), _ptr(out))
+        return self.unpack(out)
+
+    def get_twiddles(self, n, inverse=False):
+        out = np.empty((n // 2) * self.W, dtype=np.uint64)
+        self._fn("get_twiddles")(_ptr(out), _u64(n), ctypes.c_int(int(inverse)))
+        return out
+
+    def evaluate_poly(self, p, D=1):
+        v = _u64arr(p).copy()
+        self._fn("evaluate_poly")(_ptr(v), _u64(v.size // (D * self.W)), ctypes.c_uint(D))
+        return v
+
+    def interpolate_poly(self, ev, D=1):
+        v = _u64arr(ev).copy()
+        self._fn("interpolate_poly")(_ptr(v), _u64(v.size // (D * self.W)), ctypes.c_uint(D))
+        return v
+
+    def evaluate_poly_with_offset(self, p, offset, blowup, D=1):
+        v = _u64arr(p)
+        n = v.size // (D * self.W)
+        out = np.empty(n * blowup * D * self.W, dtype=np.uint64)
+        po = self.pack([offset])
+        self._fn("evaluate_poly_with_offset")(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(po), _u64(blowup), _ptr(out))
+        return out
+
+    def interpolate_poly_with_offset(self, ev, offset, D=1):
+        v = _u64arr(ev).copy()
+        po = self.pack([offset])
+        self._fn("interpolate_poly_with_offset")(_ptr(v), _u64(v.size // (D * self.W)), ctypes.c_uint(D), _ptr(po))
+        return v
+
+    def poly_eval(self, p, x):
+        v = _u64arr(p)
+        out = np.empty(self.W, dtype=np.uint64)
+        px = self.pack([x])
+        self._fn("poly_eval")(_ptr(v), _u64(v.size // self.W), _ptr(px), _ptr(out))
+        return self.unpack(out)[0]
+
+    def build_trace_commitment(self, hasher, trace, blowup, offset, D=1, num_partitions=1, hash_rate=1):
+        """trace: (c, n*D*W) uint64.  Returns (polys, lde (N, row_width*W), leaves, nodes)."""
+        polys = _u64arr(trace).copy()
+        c = polys.shape[0]
+        n = polys.shape[1] // (D * self.W)
+        N, rw = n * blowup, row_width(c * D)
+        lde = np.empty((N, rw * self.W), dtype=np.uint64)
+        leaves, nodes = np.empty((N, 32), dtype=np.uint8), np.empty((N, 32), dtype=np.uint8)
+        fn = self._fn("build_trace_commitment")
+        fn.restype = ctypes.c_int
+        po = self.pack([offset])
+        rc = fn(ctypes.c_int(hasher), _ptr(polys), _u64(c), _u64(n), ctypes.c_uint(D), _u64(blowup), _ptr(po),
+                _u64(num_partitions), _u64(hash_rate), _ptr(lde), _ptr(leaves), _ptr(nodes))
+        assert rc == 0
+        return polys, lde, leaves, nodes
+
+    def transpose_slice(self, src, N, D=1):
+        v = _u64arr(src)
+        out = np.empty_like(v)
+        self._fn("transpose_slice")(_ptr(v), _u64(v.size // (D * self.W)), ctypes.c_uint(D), _u64(N), _ptr(out))
+        return out
+
+    def fri_layer_commit(self, hasher, transposed, N, D=1):
+        v = _u64arr(transposed)
+        rows = v.size // (N * D * self.W)
+        leaves, nodes = np.empty((rows, 32), dtype=np.uint8), np.empty((rows, 32), dtype=np.uint8)
+        fn = self._fn("fri_layer_commit")
+        fn.restype = ctypes.c_int
+        assert fn(ctypes.c_int(hasher), _ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _ptr(leaves), _ptr(nodes)) == 0
+        return leaves, nodes
+
+    def apply_drp(self, transposed, N, offset, alpha, D=1):
+        v = _u64arr(transposed)
+        rows = v.size // (N * D * self.W)
+        out = np.empty(rows * D * self.W, dtype=np.uint64)
+        po, pa = self.pack([offset]), _u64arr(alpha)
+        self._fn("apply_drp")(_ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _ptr(po), _ptr(pa), _ptr(out))
+        return out
+
+
+F128_M = 2**128 - 45 * 2**40 + 1
+f128 = GenericField("f128", 2, F128_M)
+f64t = GenericField("f64t", 1, M)

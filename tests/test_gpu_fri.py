@@ -97,7 +97,8 @@ def test_build_layers_vs_oracle(wf, oracle, hname, D, log_len, N, rem_deg):
 def test_full_size_fold_properties(wf, oracle):
     """BASELINE config 5 size (2^24 LDE domain, quadratic extension, folding 4, rem-deg 31 => 8 layers down to 2^8):
     DRP folding == coefficient-form folding (fri/src/folding/mod.rs:46-85 doctest, iterated over all layers), checked
-    through the remainder polynomial, with the alphas replayed from the layer roots."""
+    through the remainder polynomial, with the alphas replayed from the layer roots.  The constant-offset convention
+    of the reference (same B::GENERATOR offset at every layer) is modelled explicitly."""
     ctx, crypto, fri, fields = wf
     from winterfell_amd.math import fft
     D, N, blowup, log_len = 2, 4, 8, 24
