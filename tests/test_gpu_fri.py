@@ -121,6 +121,13 @@ def test_full_size_fold_properties(wf, oracle):
             t0 = (acc0 * a0 - 2 * acc1 * a1) % P
             t1 = (acc0 * a1 + acc1 * a0 + acc1 * a1) % P
             acc0, acc1 = (t0 + c[j::N, 0]) % P, (t1 + c[j::N, 1]) % P
-        c = np.stack([acc0, acc1], axis=1)
+        # the reference folds every layer with the SAME domain offset o (fri/src/prover/mod.rs:216), i.e. it reads the
+        # folded values (which lie on the coset o^N * <g>) as if they lay on o * <g>: coefficient m picks up o^((N-1) m)
+        s_ = pow(7, N - 1, P)
+        scale, cu = np.empty(len(acc0), dtype=object), 1
+        for m in range(len(acc0)):
+            scale[m] = cu
+            cu = cu * s_ % P
+        c = np.stack([(acc0 * scale) % P, (acc1 * scale) % P], axis=1)
     want = fields.from_ints(c[::-1].astype(np.uint64))
     assert np.array_equal(prover.remainder_poly, want)
