@@ -1,0 +1,149 @@
+"""GPU parity for the f128 base field (math/src/field/f128) and its quadratic extension: NTTs, trace LDE + Blake3
+commitment (BASELINE configs 3a / 4 shapes), FRI — vs the CPU oracle (bit-exact canonical u128 values)."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+M128 = 2**128 - 45 * 2**40 + 1
+
+
+def _rand128(seed, n):
+    rng = np.random.default_rng(seed)
+    a = rng.integers(0, 2**64, n, dtype=np.uint64).astype(object)
+    b = rng.integers(0, 2**64, n, dtype=np.uint64).astype(object)
+    vals = ((a << 64) | b) % M128
+    out = np.empty((n, 2), dtype=np.uint64)
+    out[:, 0] = (vals & 0xFFFFFFFFFFFFFFFF).astype(np.uint64)
+    out[:, 1] = (vals >> 64).astype(np.uint64)
+    return out.reshape(-1)
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, fri, prover
+    from winterfell_amd.math import fft, fields
+    return winterfell_amd.default_context(), crypto, prover, fri, fft, fields
+
+
+def test_twiddles(wf, oracle):
+    ctx, _, _, _, fft, fields = wf
+    for n in (2, 16, 1 << 10, 1 << 14):
+        assert np.array_equal(ctx.to_host(fft.get_twiddles(n, field=fields.f128)), oracle.f128.get_twiddles(n))
+        assert np.array_equal(ctx.to_host(fft.get_inv_twiddles(n, field=fields.f128)), oracle.f128.get_twiddles(n, inverse=True))
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 12, 13, 16, 17])
+def test_evaluate_interpolate_vs_oracle(wf, oracle, log_n):
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f128, oracle.f128
+    n = 1 << log_n
+    p = _rand128(log_n, n)
+    got = fft.evaluate_poly(p.copy(), field=f)
+    assert np.array_equal(got, of.evaluate_poly(p)), log_n
+    assert np.array_equal(fft.interpolate_poly(got.copy(), field=f), p)
+    assert np.array_equal(fft.interpolate_poly(p.copy(), field=f), of.interpolate_poly(p))
+
+
+def test_edge_values_and_extension(wf, oracle):
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f128, oracle.f128
+    n = 256
+    for v in (0, 1, M128 - 1):
+        p = f.pack([v] * n)
+        assert np.array_equal(fft.evaluate_poly(p.copy(), field=f), of.evaluate_poly(p))
+    p = _rand128(7, n * 2)          # quadratic extension elements
+    assert np.array_equal(fft.evaluate_poly(p.copy(), ext_degree=2, field=f), of.evaluate_poly(p, D=2))
+    assert np.array_equal(fft.evaluate_poly_with_offset(p, None, 3, 8, ext_degree=2, field=f), of.evaluate_poly_with_offset(p, 3, 8, D=2))
+    assert np.array_equal(fft.interpolate_poly_with_offset(p.copy(), None, 3, ext_degree=2, field=f), of.interpolate_poly_with_offset(p, 3, D=2))
+    with pytest.raises(Exception):  # no cubic extension for f128 (math/src/field/f128/mod.rs:288-308)
+        fft.evaluate_poly(_rand128(1, 8 * 3), ext_degree=3, field=f)
+
+
+@pytest.mark.parametrize("log_n,blowup", [(1, 2), (6, 8), (11, 8), (14, 4)])
+def test_with_offset(wf, oracle, log_n, blowup):
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f128, oracle.f128
+    p = _rand128(log_n + blowup, 1 << log_n)
+    for off in (3, M128 - 1):
+        assert np.array_equal(fft.evaluate_poly_with_offset(p, None, off, blowup, field=f), of.evaluate_poly_with_offset(p, off, blowup))
+    assert np.array_equal(fft.interpolate_poly_with_offset(p.copy(), None, 3, field=f), of.interpolate_poly_with_offset(p, 3))
+
+
+def test_blake3_hash_elements_raw_bytes(wf, oracle):
+    ctx, crypto, _, _, _, fields = wf
+    for n in (0, 1, 2, 3, 4, 5, 31, 32, 33, 63, 64, 65, 100, 128, 200):   # 64 elements = one BLAKE3 chunk
+        e = _rand128(n + 1, n) if n else np.zeros(0, dtype=np.uint64)
+        assert crypto.Blake3_256.hash_elements(e, field=fields.f128).tobytes() == oracle.blake3(e.tobytes()), n
+
+
+@pytest.mark.parametrize("c,log_n,blowup,parts,D", [
+    (4, 10, 8, 1, 1),      # examples::rescue shape (config 3a): 4 f128 columns, Blake3_256
+    (9, 8, 4, 1, 1),
+    (64, 6, 8, 8, 1),      # config 4 shape: 64 columns, PartitionOptions(8, .) => 8 columns per partition
+    (3, 9, 8, 1, 2),       # aux segment over the quadratic extension
+    (2, 13, 8, 1, 1),
+])
+def test_build_trace_commitment_vs_oracle(wf, oracle, c, log_n, blowup, parts, D):
+    ctx, crypto, prover, _, _, fields = wf
+    f, of = fields.f128, oracle.f128
+    n = 1 << log_n
+    trace = _rand128(c * 100 + log_n, n * c * D).reshape(c, n * D * 2)
+    po = prover.PartitionOptions(parts, 4)
+    dom = prover.StarkDomain(n, blowup, field=f)
+    assert dom.offset == 3
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace, ext_degree=D, field=f), dom, po)
+    o_polys, o_lde, o_leaves, o_nodes = of.build_trace_commitment(0, trace, blowup, 3, D=D, num_partitions=parts, hash_rate=4)
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    assert np.array_equal(lde.to_host(), o_lde), "lde"
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"
+    assert np.array_equal(lde.rows([1, 5]), o_lde[[1, 5], : c * D * 2])
+    with pytest.raises(Exception):   # Rp64_256 is defined over f64 only
+        prover.build_trace_commitment(crypto.Rp64_256, prover.ColMatrix(trace, ext_degree=D, field=f), dom, po)
+
+
+@pytest.mark.parametrize("D,N", [(1, 4), (2, 4), (2, 2), (1, 16), (2, 8)])
+def test_fri_layers_vs_oracle(wf, oracle, D, N):
+    """fri/benches/prover.rs runs FRI over f128 with Blake3: layer commitments and DRP folds vs the oracle."""
+    ctx, crypto, _, fri, fft, fields = wf
+    from winterfell_amd._lib import ptr
+    f, of = fields.f128, oracle.f128
+    log_len, blowup = 11, 8
+    n = (1 << log_len) // blowup
+    ev = of.evaluate_poly_with_offset(_rand128(D * 10 + N, n * D), 3, blowup, D=D)
+    rows = (1 << log_len) // N
+    tr, leaves, nodes = ctx.empty_u64(rows, N * D * 2), ctx.empty_u8(rows, 32), ctx.empty_u8(rows, 32)
+    root = np.empty(32, dtype=np.uint8)
+    ctx.call("wf_fri_layer_commit", 0, f.ID, D, ptr(ctx.to_device(ev)), log_len, N, ptr(tr), ptr(leaves), ptr(nodes),
+             root.ctypes.data_as(ctypes.c_void_p))
+    o_tr = of.transpose_slice(ev, N, D)
+    o_leaves, o_nodes = of.fri_layer_commit(0, o_tr, N, D)
+    assert np.array_equal(ctx.to_host(tr).reshape(-1), o_tr)
+    assert np.array_equal(ctx.to_host(nodes), o_nodes) and np.array_equal(root, o_nodes[1])
+    alpha = _rand128(5, D)
+    off = f.element_words(3)
+    folded = ctx.empty_u64(rows * D * 2)
+    ctx.call("wf_fri_apply_drp", f.ID, D, ptr(tr), log_len, N, off.ctypes.data_as(ctypes.c_void_p),
+             alpha.ctypes.data_as(ctypes.c_void_p), ptr(folded))
+    assert np.array_equal(ctx.to_host(folded), of.apply_drp(o_tr, N, 3, alpha, D))
+
+
+def test_full_size_properties(wf, oracle):
+    """2^20-point f128 NTT (config 3a trace length): round trip and Horner spot values."""
+    ctx, _, _, _, fft, fields = wf
+    import torch
+    f, of = fields.f128, oracle.f128
+    log_n = 20
+    n = 1 << log_n
+    p = _rand128(99, n)
+    dp = ctx.to_device(p)
+    ev = fft.evaluate_poly(dp.clone(), field=f)
+    assert torch.equal(fft.interpolate_poly(ev.clone(), field=f), dp)
+    host = f.unpack(ctx.to_host(ev)[: 2 * 4]) + f.unpack(ctx.to_host(ev)[2 * (n - 1):])
+    w = of.root_of_unity(log_n)
+    for val, k in zip(host, (0, 1, 2, 3, n - 1)):
+        assert val == of.poly_eval(p, pow(w, k, M128)), k

@@ -28,20 +28,20 @@ class _Hasher:
         return out[0] if v.size == 64 else out
 
     @classmethod
-    def hash_elements(cls, elements, ctx=None):
+    def hash_elements(cls, elements, ctx=None, field=fields.f64):
         """ElementHasher::hash_elements — elements: base-field words in internal form (extension elements
-        flattened).  A 2-D array hashes each row."""
+        flattened; field.W u64 words per base element).  A 2-D array hashes each row."""
         ctx = ctx or default_context()
         e = np.ascontiguousarray(elements, dtype=np.uint64)
         rows = e.reshape(1, -1) if e.ndim == 1 else e
         if rows.shape[1] == 0:
-            rows = np.zeros((rows.shape[0], 1), dtype=np.uint64)
+            rows = np.zeros((rows.shape[0], field.W), dtype=np.uint64)
             width, take = 1, 0
         else:
-            width, take = rows.shape[1], rows.shape[1]
+            width = take = rows.shape[1] // field.W
         d_in = ctx.to_device(rows)
         d_out = ctx.empty_u8(rows.shape[0], 32)
-        ctx.call("wf_hash_elements_batch", cls.HASH_ID, WF_FIELD_F64, ptr(d_in), rows.shape[0], width, take, ptr(d_out))
+        ctx.call("wf_hash_elements_batch", cls.HASH_ID, field.ID, ptr(d_in), rows.shape[0], width, take, ptr(d_out))
         out = ctx.to_host(d_out)
         return out[0] if e.ndim == 1 else out
 

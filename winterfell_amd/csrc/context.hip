@@ -169,76 +169,3 @@ int wf_scratch(wf_ctx *ctx, int slot, size_t bytes, void **out) {
     return WF_OK;
 }
 
-// ---- tables ----------------------------------------------------------------------------------------
-static int upload(wf_ctx *ctx, const std::vector<uint64_t> &h, uint64_t **d) {
-    void *p;
-    WF_HIP(hipMalloc(&p, h.size() * sizeof(uint64_t)));
-    ctx->owned.push_back(p);
-    WF_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
-    WF_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope in the caller
-    *d = (uint64_t *)p;
-    return WF_OK;
-}
-
-// series scale * base^i, i < 2^log_len, split lo (2^log_lo entries: base^i) x hi (scale * base^(i << log_lo))
-static void build_series(uint64_t base, uint64_t scale, uint32_t log_len, uint32_t log_lo, std::vector<uint64_t> &lo,
-                         std::vector<uint64_t> &hi) {
-    using namespace hostgl;
-    const uint64_t nlo = 1ull << log_lo, nhi = 1ull << (log_len - log_lo);
-    lo.resize(nlo);
-    hi.resize(nhi);
-    uint64_t cur = 1;
-    for (uint64_t i = 0; i < nlo; i++) {
-        lo[i] = to_mont(cur);
-        cur = mulmod(cur, base);
-    }
-    const uint64_t step = cur;  // base^(2^log_lo)
-    cur = scale;
-    for (uint64_t i = 0; i < nhi; i++) {
-        hi[i] = to_mont(cur);
-        cur = mulmod(cur, step);
-    }
-}
-
-int wf_get_series_table(wf_ctx *ctx, uint64_t base, uint64_t scale, uint32_t log_len, SeriesTable *out) {
-    auto key = std::make_tuple(base, scale, log_len);
-    auto it = ctx->series.find(key);
-    if (it == ctx->series.end()) {
-        SeriesTable t;
-        t.log_len = log_len;
-        t.log_lo = log_len < 12 ? log_len : 12;
-        std::vector<uint64_t> lo, hi;
-        build_series(base, scale, log_len, t.log_lo, lo, hi);
-        WF_TRY(upload(ctx, lo, &t.d_lo));
-        WF_TRY(upload(ctx, hi, &t.d_hi));
-        it = ctx->series.emplace(key, t).first;
-    }
-    *out = it->second;
-    return WF_OK;
-}
-
-int wf_get_omega_table(wf_ctx *ctx, uint32_t log_n, SeriesTable *out) {
-    auto it = ctx->omega.find(log_n);
-    if (it == ctx->omega.end()) {
-        SeriesTable t;
-        WF_TRY(wf_get_series_table(ctx, hostgl::root_of_unity(log_n), 1, log_n, &t));
-        it = ctx->omega.emplace(log_n, t).first;
-    }
-    *out = it->second;
-    return WF_OK;
-}
-
-int wf_get_w256(wf_ctx *ctx, uint64_t **out) {
-    if (!ctx->d_w256) {
-        std::vector<uint64_t> h(256);
-        const uint64_t w = hostgl::root_of_unity(8);
-        uint64_t cur = 1;
-        for (int i = 0; i < 256; i++) {
-            h[i] = hostgl::to_mont(cur);
-            cur = hostgl::mulmod(cur, w);
-        }
-        WF_TRY(upload(ctx, h, &ctx->d_w256));
-    }
-    *out = ctx->d_w256;
-    return WF_OK;
-}

@@ -6,15 +6,16 @@
 //   fold:         per row i: N-point inverse DFT of t[i], coefficient k scaled by (1/N) * (offset^-1 * g^-i)^k,
 //                 Horner evaluation at alpha  (apply_drp); the same domain offset is used at every layer (mod.rs:216)
 // Layers are inherently sequential (alpha_k depends on root_k): the host draws alpha between the two calls.
+#include <string.h>
+
 #include "dft_regs.cuh"
-#include "gl64.cuh"
+#include "tables.cuh"
 #include "wf_internal.h"
 
 namespace {
 
-template <int D>
-__global__ __launch_bounds__(256) void fri_transpose_kernel(const uint64_t *ev, uint64_t *out, uint32_t log_rc,
-                                                            uint32_t log_nf) {
+template <class T, int D>
+__global__ __launch_bounds__(256) void fri_transpose_kernel(const T *ev, T *out, uint32_t log_rc, uint32_t log_nf) {
     // one row per lane: reads are coalesced along i for every j; a row (N*D words) is written contiguously
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t rc = 1ull << log_rc;
@@ -26,62 +27,76 @@ __global__ __launch_bounds__(256) void fri_transpose_kernel(const uint64_t *ev, 
     }
 }
 
-template <int LOG_NF, int D>
-__global__ __launch_bounds__(256) void fri_fold_kernel(const uint64_t *t, uint64_t *out, uint32_t log_rc,
-                                                       const uint64_t *io_lo, const uint64_t *io_hi, uint32_t io_log_lo,
-                                                       uint64_t inv_n, uint64_t a0, uint64_t a1, uint64_t a2) {
+template <class T>
+struct FoldConsts {
+    T inv_n;
+    T alpha[3];
+};
+
+template <class F, int LOG_NF, int D>
+__global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, typename F::T *out, uint32_t log_rc,
+                                                       const typename F::T *io_lo, const typename F::T *io_hi,
+                                                       uint32_t io_log_lo, const typename F::T *w16,
+                                                       FoldConsts<typename F::T> cst) {
+    typedef typename F::T T;
     constexpr int N = 1 << LOG_NF;
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (1ull << log_rc)) return;
-    uint64_t comp[D][N];
+    T comp[D][N];
 #pragma unroll
     for (int j = 0; j < N; j++)
 #pragma unroll
         for (int d = 0; d < D; d++) comp[d][j] = t[(i * N + j) * D + d];
     // forward DFT per component (bit-reversed registers); inverse coefficient k = X[(N - k) mod N]
 #pragma unroll
-    for (int d = 0; d < D; d++) dft_dif<LOG_NF>(comp[d]);
-    const uint64_t io = series_at(io_lo, io_hi, io_log_lo, i);   // offset^-1 * g^-i
-    uint64_t scale[N];
-    scale[0] = inv_n;
+    for (int d = 0; d < D; d++) dft_dif<F, LOG_NF>(comp[d], w16);
+    const T io = series_at<F>(io_lo, io_hi, io_log_lo, i);   // offset^-1 * g^-i
+    T scale[N];
+    scale[0] = cst.inv_n;
 #pragma unroll
-    for (int k = 1; k < N; k++) scale[k] = gl::mul(scale[k - 1], io);
-    const uint64_t alpha[3] = {a0, a1, a2};
-    uint64_t al[D], acc[D];
+    for (int k = 1; k < N; k++) scale[k] = F::mul(scale[k - 1], io);
+    T al[D], acc[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) { al[d] = alpha[d]; acc[d] = 0; }
+    for (int d = 0; d < D; d++) { al[d] = cst.alpha[d]; acc[d] = F::zero(); }
 #pragma unroll
     for (int k = N - 1; k >= 0; k--) {
-        uint64_t tmp[D];
-        gl::ext_mul<D>(acc, al, tmp);
+        T tmp[D];
+        F::template ext_mul<D>(acc, al, tmp);
         const int src = brev((N - k) & (N - 1), LOG_NF);
 #pragma unroll
-        for (int d = 0; d < D; d++) acc[d] = gl::add(tmp[d], gl::mul(comp[d][src], scale[k]));
+        for (int d = 0; d < D; d++) acc[d] = F::add(tmp[d], F::mul(comp[d][src], scale[k]));
     }
 #pragma unroll
     for (int d = 0; d < D; d++) out[i * D + d] = acc[d];
 }
 
-template <int D>
-int launch_fold(wf_ctx *ctx, uint32_t log_nf, const uint64_t *t, uint64_t *out, uint32_t log_rc, const SeriesTable &io,
-                uint64_t inv_n, const uint64_t *alpha) {
+template <class HF, int D>
+int launch_fold(wf_ctx *ctx, uint32_t log_nf, const void *t_, void *out_, uint32_t log_rc, const SeriesTable &io,
+                const FoldConsts<typename HF::T> &cst) {
+    typedef typename HF::Dev F;
+    typedef typename F::T T;
+    const T *t = (const T *)t_;
+    T *out = (T *)out_;
+    const T *lo = (const T *)io.d_lo, *hi = (const T *)io.d_hi;
+    void *w256, *w16v;
+    WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16v));
+    const T *w16 = (const T *)w16v;
     const uint64_t rc = 1ull << log_rc;
     const dim3 grid((uint32_t)((rc + 255) / 256)), block(256);
-    const uint64_t a0 = alpha[0], a1 = D > 1 ? alpha[1] : 0, a2 = D > 2 ? alpha[2] : 0;
     wf_prof_begin(ctx, "fri_fold");
     switch (log_nf) {
-        case 1: hipLaunchKernelGGL((fri_fold_kernel<1, D>), grid, block, 0, ctx->stream, t, out, log_rc, io.d_lo, io.d_hi, io.log_lo, inv_n, a0, a1, a2); break;
-        case 2: hipLaunchKernelGGL((fri_fold_kernel<2, D>), grid, block, 0, ctx->stream, t, out, log_rc, io.d_lo, io.d_hi, io.log_lo, inv_n, a0, a1, a2); break;
-        case 3: hipLaunchKernelGGL((fri_fold_kernel<3, D>), grid, block, 0, ctx->stream, t, out, log_rc, io.d_lo, io.d_hi, io.log_lo, inv_n, a0, a1, a2); break;
-        default: hipLaunchKernelGGL((fri_fold_kernel<4, D>), grid, block, 0, ctx->stream, t, out, log_rc, io.d_lo, io.d_hi, io.log_lo, inv_n, a0, a1, a2); break;
+        case 1: hipLaunchKernelGGL((fri_fold_kernel<F, 1, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
+        case 2: hipLaunchKernelGGL((fri_fold_kernel<F, 2, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
+        case 3: hipLaunchKernelGGL((fri_fold_kernel<F, 3, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
+        default: hipLaunchKernelGGL((fri_fold_kernel<F, 4, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
     }
     wf_prof_end(ctx);
     WF_HIP(hipGetLastError());
     return WF_OK;
 }
 
-int check_args(int field, uint32_t D, uint32_t log_len, uint32_t folding, uint32_t *log_nf) {
-    if (field != WF_FIELD_F64 || D < 1 || D > 3) return WF_ERR_UNSUPPORTED;
+int check_args(uint32_t max_ext, uint32_t D, uint32_t log_len, uint32_t folding, uint32_t *log_nf) {
+    if (D < 1 || D > max_ext) return WF_ERR_UNSUPPORTED;
     if (folding != 2 && folding != 4 && folding != 8 && folding != 16) return WF_ERR_UNSUPPORTED;  // mod.rs:187-195
     uint32_t l = 0;
     while ((1u << l) < folding) l++;
@@ -90,54 +105,76 @@ int check_args(int field, uint32_t D, uint32_t log_len, uint32_t folding, uint32
     return WF_OK;
 }
 
+template <class HF>
+int layer_commit(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_t log_len, uint32_t folding, void *d_transposed,
+                 void *d_leaves, void *d_nodes, void *h_root) {
+    typedef typename HF::T T;
+    uint32_t log_nf;
+    WF_TRY(check_args(HF::Dev::MAX_EXT, D, log_len, folding, &log_nf));
+    const uint32_t log_rc = log_len - log_nf;
+    const uint64_t rc = 1ull << log_rc;
+    const dim3 grid((uint32_t)((rc + 255) / 256)), block(256);
+    const T *ev = (const T *)d_evals;
+    T *tr = (T *)d_transposed;
+    wf_prof_begin(ctx, "fri_transpose");
+    if (D == 1) hipLaunchKernelGGL((fri_transpose_kernel<T, 1>), grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
+    else if (D == 2) hipLaunchKernelGGL((fri_transpose_kernel<T, 2>), grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
+    else hipLaunchKernelGGL((fri_transpose_kernel<T, 3>), grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    const uint32_t row_elems = folding * D;
+    // build_layer_commitment: leaf = hash_elements(row); V::new(leaves)
+    WF_TRY(wf_hash_elements_batch(ctx, hash, HF::Dev::ID, d_transposed, rc, row_elems, row_elems, d_leaves));
+    WF_TRY(wf_merkle_build(ctx, hash, d_leaves, rc, d_nodes));
+    if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_nodes + 32, 32));
+    return WF_OK;
+}
+
+template <class HF>
+int apply_drp(wf_ctx *ctx, uint32_t D, const void *d_transposed, uint32_t log_len, uint32_t folding, const void *h_domain_offset,
+              const void *h_alpha, void *d_folded) {
+    typedef typename HF::T T;
+    uint32_t log_nf;
+    WF_TRY(check_args(HF::Dev::MAX_EXT, D, log_len, folding, &log_nf));
+    const uint32_t log_rc = log_len - log_nf;
+    T off;
+    WF_TRY(wf_load_offset<HF>(h_domain_offset, &off));
+    // inv_offsets[i] = offset^-1 * (g^-1)^i, g = root of unity of the layer's domain (folding/mod.rs:181-188)
+    SeriesTable io;
+    const T g_inv = HF::invmod(HF::root_of_unity(log_len));
+    WF_TRY(wf_get_series_table<HF>(ctx, g_inv, HF::invmod(off), log_rc, &io));
+    FoldConsts<T> cst;
+    cst.inv_n = HF::to_internal(HF::invmod(HF::from_u64(folding)));
+    for (uint32_t d = 0; d < 3; d++) cst.alpha[d] = 0;
+    for (uint32_t d = 0; d < D; d++) {
+        memcpy(&cst.alpha[d], (const uint8_t *)h_alpha + d * sizeof(T), sizeof(T));
+        if (!HF::valid_internal(cst.alpha[d])) return WF_ERR_INVALID_ARG;
+    }
+    if (D == 1) return launch_fold<HF, 1>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
+    if (D == 2) return launch_fold<HF, 2>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
+    if constexpr (HF::Dev::MAX_EXT >= 3) return launch_fold<HF, 3>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
+    return WF_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 
 extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals,
                                    uint32_t log_len, uint32_t folding, void *d_transposed, void *d_leaves, void *d_nodes,
                                    void *h_root) {
     if (!ctx || !d_evals || !d_transposed || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
-    uint32_t log_nf;
-    WF_TRY(check_args(field, ext_degree, log_len, folding, &log_nf));
-    const uint32_t log_rc = log_len - log_nf;
-    const uint64_t rc = 1ull << log_rc;
-    const dim3 grid((uint32_t)((rc + 255) / 256)), block(256);
-    const uint64_t *ev = (const uint64_t *)d_evals;
-    uint64_t *tr = (uint64_t *)d_transposed;
-    wf_prof_begin(ctx, "fri_transpose");
-    if (ext_degree == 1) hipLaunchKernelGGL(fri_transpose_kernel<1>, grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
-    else if (ext_degree == 2) hipLaunchKernelGGL(fri_transpose_kernel<2>, grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
-    else hipLaunchKernelGGL(fri_transpose_kernel<3>, grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
-    wf_prof_end(ctx);
-    WF_HIP(hipGetLastError());
-    const uint32_t row_words = folding * ext_degree;
-    // build_layer_commitment: leaf = hash_elements(row); V::new(leaves)
-    WF_TRY(wf_hash_elements_batch(ctx, hash, field, d_transposed, rc, row_words, row_words, d_leaves));
-    WF_TRY(wf_merkle_build(ctx, hash, d_leaves, rc, d_nodes));
-    if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_nodes + 32, 32));
-    return WF_OK;
+    switch (field) {
+        case WF_FIELD_F64: return layer_commit<HostF64>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
+        case WF_FIELD_F128: return layer_commit<HostF128>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
+        default: return WF_ERR_UNSUPPORTED;
+    }
 }
 
 extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                                 uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
     if (!ctx || !d_transposed || !h_domain_offset || !h_alpha || !d_folded) return WF_ERR_INVALID_ARG;
-    uint32_t log_nf;
-    WF_TRY(check_args(field, ext_degree, log_len, folding, &log_nf));
-    const uint32_t log_rc = log_len - log_nf;
-    const uint64_t off_m = *(const uint64_t *)h_domain_offset;
-    if (off_m >= hostgl::P) return WF_ERR_INVALID_ARG;
-    const uint64_t off = hostgl::from_mont(off_m);
-    if (off == 0) return WF_ERR_ZERO_OFFSET;
-    // inv_offsets[i] = offset^-1 * (g^-1)^i, g = root of unity of the layer's domain (folding/mod.rs:181-188)
-    SeriesTable io;
-    const uint64_t g_inv = hostgl::invmod(hostgl::root_of_unity(log_len));
-    WF_TRY(wf_get_series_table(ctx, g_inv, hostgl::invmod(off), log_rc == 0 ? 0 : log_rc, &io));
-    const uint64_t inv_n = hostgl::to_mont(hostgl::invmod(folding));
-    const uint64_t *alpha = (const uint64_t *)h_alpha;
-    for (uint32_t d = 0; d < ext_degree; d++)
-        if (alpha[d] >= hostgl::P) return WF_ERR_INVALID_ARG;
-    const uint64_t *t = (const uint64_t *)d_transposed;
-    uint64_t *out = (uint64_t *)d_folded;
-    if (ext_degree == 1) return launch_fold<1>(ctx, log_nf, t, out, log_rc, io, inv_n, alpha);
-    if (ext_degree == 2) return launch_fold<2>(ctx, log_nf, t, out, log_rc, io, inv_n, alpha);
-    return launch_fold<3>(ctx, log_nf, t, out, log_rc, io, inv_n, alpha);
+    switch (field) {
+        case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
+        case WF_FIELD_F128: return apply_drp<HostF128>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
+        default: return WF_ERR_UNSUPPORTED;
+    }
 }

@@ -76,19 +76,19 @@ __device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
     static_assert(S > 0 && S < 96, "shift out of range");
     uint64_t lo, hi;
     uint32_t mid;
-    if (S < 32) {
+    if constexpr (S < 32) {
         lo = x << S;
         mid = (uint32_t)(x >> (64 - S));
         hi = 0;
-    } else if (S == 32) {
+    } else if constexpr (S == 32) {
         lo = x << 32;
         mid = (uint32_t)(x >> 32);
         hi = 0;
-    } else if (S < 64) {
+    } else if constexpr (S < 64) {
         lo = x << S;
         mid = (uint32_t)(x >> (64 - S));
         hi = x >> (96 - S);
-    } else if (S == 64) {
+    } else if constexpr (S == 64) {
         lo = 0;
         mid = (uint32_t)x;
         hi = x >> 32;

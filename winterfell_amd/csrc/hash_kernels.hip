@@ -237,16 +237,23 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
                           void *d_leaves) {
     if (!ctx || !d_rows || !d_leaves || num_rows == 0 || D == 0) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
-    if (field != WF_FIELD_F64) return WF_ERR_UNSUPPORTED;
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return WF_ERR_UNSUPPORTED;
+    if (field == WF_FIELD_F128 && hash == WF_HASH_RP64_256) return WF_ERR_UNSUPPORTED;   // Rp64_256 is defined over f64 only
     if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
     if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
-    const int mode = MODE_F64_CANON;
+    // f64 is not IS_CANONICAL: hash the canonical LE bytes; f128 is: hash the raw element bytes (blake/mod.rs:52-65).
+    // Rows are addressed in 64-bit words: an f128 element is two words.
+    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : MODE_RAW;
+    const uint32_t W = field == WF_FIELD_F128 ? 2 : 1;
+    row_width *= W;
+    elems_per_row *= W;
+    D *= W;
     const uint64_t *rows = (const uint64_t *)d_rows;
     // PartitionOptions::partition_size / num_partitions — air/src/options.rs:428-444 (in columns of E)
     const uint32_t num_cols = elems_per_row / D;
     uint32_t ps = num_cols;
     if (num_partitions > 1) {
-        const uint32_t min_ps = hash_rate / D;
+        const uint32_t min_ps = hash_rate / (D / W);
         ps = (num_cols + num_partitions - 1) / num_partitions;
         if (ps < min_ps) ps = min_ps;
     }

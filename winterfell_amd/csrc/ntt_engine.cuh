@@ -1,0 +1,319 @@
+// NTT engine for gfx950, generic over the field policy (fields.cuh); the design notes below are written for
+// f64 (Goldilocks), where the register-DFT twiddles are shifts; other fields use table constants instead.
+//
+// Computes what the reference's math::fft computes (math/src/fft/mod.rs:85-386, serial.rs, concurrent.rs,
+// fft_inputs.rs:215-252): natural-order in, natural-order out DFTs over the 2^k-th roots of unity of the
+// f64 field, with optional coset scaling on the input (evaluate_poly_with_offset) or output
+// (interpolate_poly_with_offset).  The reference's recursive radix-2 butterflies + bit-reversal permute
+// are NOT mirrored: field arithmetic is exact, so any DFT algorithm yields the same canonical values.
+//
+// Algorithm: a transform of n = 2^L points is split into P = ceil(L/8) passes of radix R_p = 2^(r_p)
+// (r_p <= 8, decimation in frequency, most significant index digit first).  One pass =
+//   - each 256-thread workgroup owns a tile of R_p "rows" (stride S_p = n / (R_1..R_p)) x T "columns";
+//     a thread holds A = 2^LOG_A elements in registers and runs an A-point DFT whose internal twiddles
+//     are powers of omega_16 = 2^12 (shifts, no multiplies; omega_64 = 8 in this field, f64/mod.rs:258-267),
+//   - multiplies by omega_{R_p}^(k_a * b), exchanges through LDS (padded, conflict-free),
+//   - runs the B-point DFT, multiplies by the inter-pass twiddle omega_n^(...) from a two-level table,
+//   - stores.  Passes 1..P-1 store in place (tile rows at the same addresses, coalesced along the
+//     columns); the last pass runs along the contiguous axis and stores digit-reversed so that the
+//     result is in natural order (coalesced along the tile's columns, which are the low output digits).
+// The inverse transform is the forward transform with the output index negated (k -> -k mod n) and a
+// 1/n scale, so only forward tables exist.
+//
+// HBM traffic: P reads + P writes of the data (P = 3 at n = 2^24), see DESIGN.md.
+#pragma once
+#include <string.h>
+
+#include "dft_regs.cuh"
+#include "tables.cuh"
+#include "wf_internal.h"
+
+namespace {
+
+template <class T>
+struct PassParams {
+    const T *src;
+    T *dst;
+    uint32_t log_n;
+    uint32_t npass;
+    uint32_t pass;
+    uint32_t log_r[4];
+    uint32_t nvec;
+    uint32_t src_div, src_inner, dst_inner;
+    uint64_t src_vec_stride, dst_vec_stride;
+    uint64_t src_inner_stride, dst_inner_stride;
+    uint32_t src_es, dst_es;
+    uint32_t inverse;
+    // tables
+    const T *w_lo, *w_hi;
+    uint32_t w_log_lo;
+    const T *w256, *w16;
+    const T *pre_lo, *pre_hi;
+    uint32_t pre_log_lo, pre_mod;
+    uint64_t pre_lo_stride, pre_hi_stride;
+    const T *post_lo, *post_hi;
+    uint32_t post_log_lo;
+    uint32_t has_post_const;
+    T post_const;
+};
+
+#ifndef NTT_WAVES_PER_EU
+#define NTT_WAVES_ATTR
+#else
+#define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_WAVES_PER_EU, NTT_WAVES_PER_EU)))
+#endif
+
+template <class F, int LOG_A, int LOG_B, bool LAST>
+__global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typename F::T> p) {
+    typedef typename F::T T;
+    constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
+    constexpr int TC = 256 / B;         // tile columns
+    constexpr int G = A / B;            // B-point DFTs per thread in step 2
+    static_assert(B == 1 || G == 1 || G == 2, "A must be B or 2B");
+    // LDS exchange buffer: non-last [k_a][b][t] with padded k_a rows; last [k_a][t][b] with padded b rows
+    constexpr int ROW_NL = B * TC + 16;
+    constexpr int ROW_L = B + 1;
+    constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * TC * ROW_L : A * ROW_NL);
+    __shared__ T lds[LDS_ELEMS];
+
+    const int tid = threadIdx.x;
+    const uint32_t L = p.log_n;
+    const uint64_t n = 1ull << L;
+    const uint64_t ncols = n >> LOG_R;                     // columns per vector
+    const uint64_t total_cols = ncols * (uint64_t)p.nvec;  // joint (vector, column) space
+    const uint64_t cc0 = (uint64_t)blockIdx.x * TC;
+
+    // log2 of this digit's stride S_p
+    uint32_t log_s = L;
+    for (uint32_t q = 0; q <= p.pass; q++) log_s -= p.log_r[q];
+    const uint32_t log_mult = L - log_s - LOG_R;           // n / n_p = R_1..R_{p-1}
+
+    // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
+    int b1, t1;
+    if (!LAST) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
+    T x[A];
+    {
+        const uint64_t cc = cc0 + t1;
+        const bool active = cc < total_cols;
+        const uint64_t v = active ? cc / ncols : 0;
+        const uint64_t c = active ? cc % ncols : 0;
+        uint64_t base;
+        if (!LAST) {
+            const uint64_t rem = c & ((1ull << log_s) - 1);
+            base = ((c >> log_s) << (log_s + LOG_R)) + rem;
+        } else {
+            base = 0;
+            uint64_t cr = c;
+            uint32_t ls = L;
+            for (uint32_t q = 0; q + 1 < p.npass; q++) {
+                ls -= p.log_r[q];
+                base += (cr & ((1ull << p.log_r[q]) - 1)) << ls;
+                cr >>= p.log_r[q];
+            }
+        }
+        const uint64_t vs = v / p.src_div;
+        const T *src = p.src + (vs / p.src_inner) * p.src_vec_stride + (vs % p.src_inner) * p.src_inner_stride;
+        if (active) {
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
+                x[a] = src[j * p.src_es];
+            }
+            if (p.pre_lo != nullptr && p.pass == 0) {
+                const uint32_t u = (uint32_t)(v % p.pre_mod);
+                const T *plo = p.pre_lo + u * p.pre_lo_stride, *phi = p.pre_hi + u * p.pre_hi_stride;
+#pragma unroll
+                for (int a = 0; a < A; a++) {
+                    const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
+                    x[a] = F::mul(x[a], series_at<F>(plo, phi, p.pre_log_lo, j));
+                }
+            }
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; a++) x[a] = F::zero();
+        }
+        dft_dif<F, LOG_A>(x, p.w16);
+        if (B > 1) {
+            // intra-pass twiddle omega_R^(k_a * b) = omega_256^((k_a * b) << (8 - LOG_R)), then LDS exchange
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                const int ka = brev(i, LOG_A);
+                T val = x[i];
+                if (ka != 0) val = F::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
+                if (!LAST) lds[ka * ROW_NL + b1 * TC + t1] = val;
+                else lds[(ka * TC + t1) * ROW_L + b1] = val;
+            }
+        }
+    }
+
+    if (B > 1) __syncthreads();
+
+    // ---- step 2: B-point DFT(s) over the low half, inter-pass twiddle, store -----------------------
+    const int t2 = (B > 1) ? tid % TC : t1;
+    const int q2 = (B > 1) ? tid / TC : 0;
+    const uint64_t cc = cc0 + t2;
+    if (cc >= total_cols) return;
+    const uint64_t v = cc / ncols;
+    const uint64_t c = cc % ncols;
+    T *dst = p.dst + (v / p.dst_inner) * p.dst_vec_stride + (v % p.dst_inner) * p.dst_inner_stride;
+    const uint64_t rem = c & ((1ull << log_s) - 1);
+    const uint64_t base_nl = ((c >> log_s) << (log_s + LOG_R)) + rem;
+
+    auto emit = [&](T val, uint32_t kp) {
+        if (!LAST) {
+            if (kp != 0) {
+                const uint64_t e = ((uint64_t)kp * rem) << log_mult;
+                val = F::mul(val, series_at<F>(p.w_lo, p.w_hi, p.w_log_lo, e));
+            }
+            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val;
+        } else {
+            uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
+            if (p.inverse) k = (n - k) & (n - 1);
+            if (p.post_lo != nullptr) val = F::mul(val, series_at<F>(p.post_lo, p.post_hi, p.post_log_lo, k));
+            else if (p.has_post_const) val = F::mul(val, p.post_const);
+            dst[k * p.dst_es] = val;
+        }
+    };
+
+    if (B == 1) {
+#pragma unroll
+        for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
+    } else {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int ka = q2 + B * g;
+            T y[B];
+#pragma unroll
+            for (int bb = 0; bb < B; bb++) {
+                if (!LAST) y[bb] = lds[ka * ROW_NL + bb * TC + t2];
+                else y[bb] = lds[(ka * TC + t2) * ROW_L + bb];
+            }
+            dft_dif<F, LOG_B>(y, p.w16);
+#pragma unroll
+            for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+        }
+    }
+}
+
+template <class F, int LA, int LB>
+auto pick(bool last) -> void (*)(PassParams<typename F::T>) {
+    typedef void (*fn)(PassParams<typename F::T>);
+    return last ? (fn)ntt_pass<F, LA, LB, true> : (fn)ntt_pass<F, LA, LB, false>;
+}
+
+template <class F>
+auto kernel_for(uint32_t r, bool last) -> void (*)(PassParams<typename F::T>) {
+    switch (r) {
+        case 1: return pick<F, 1, 0>(last);
+        case 2: return pick<F, 1, 1>(last);
+        case 3: return pick<F, 2, 1>(last);
+        case 4: return pick<F, 2, 2>(last);
+        case 5: return pick<F, 3, 2>(last);
+        case 6: return pick<F, 3, 3>(last);
+        case 7: return pick<F, 4, 3>(last);
+        default: return pick<F, 4, 4>(last);
+    }
+}
+
+inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
+
+}  // namespace
+
+// Split L bits into passes of at most 8 bits, as evenly as possible (largest first).
+static inline void plan_passes(uint32_t L, uint32_t &npass, uint32_t log_r[4]) {
+    npass = (L + 7) / 8;
+    if (npass == 0) npass = 1;
+    uint32_t rem = L;
+    for (uint32_t q = 0; q < npass; q++) {
+        uint32_t left = npass - q;
+        uint32_t r = (rem + left - 1) / left;
+        log_r[q] = r;
+        rem -= r;
+    }
+    for (uint32_t q = npass; q < 4; q++) log_r[q] = 0;
+}
+
+template <class HF>
+static int ntt_run(wf_ctx *ctx, const NttJob &job) {
+    typedef typename HF::Dev F;
+    typedef typename F::T T;
+    const uint32_t L = job.log_n;
+    if (L == 0) return WF_ERR_INVALID_ARG;
+    if (L > HF::TWO_ADICITY || L > 32) return WF_ERR_DOMAIN_TOO_LARGE;
+    PassParams<T> p{};
+    p.log_n = L;
+    plan_passes(L, p.npass, p.log_r);
+    p.nvec = job.nvec;
+    p.inverse = job.inverse ? 1 : 0;
+    SeriesTable om;
+    WF_TRY(wf_get_omega_table<HF>(ctx, L, &om));
+    p.w_lo = (const T *)om.d_lo;
+    p.w_hi = (const T *)om.d_hi;
+    p.w_log_lo = om.log_lo;
+    void *w256, *w16;
+    WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16));
+    p.w256 = (const T *)w256;
+    p.w16 = (const T *)w16;
+    p.pre_lo = (const T *)job.pre_lo;
+    p.pre_hi = (const T *)job.pre_hi;
+    p.pre_log_lo = job.pre_log_lo;
+    p.pre_mod = job.pre_mod ? job.pre_mod : 1;
+    p.pre_lo_stride = job.pre_lo_stride;
+    p.pre_hi_stride = job.pre_hi_stride;
+    p.post_lo = (const T *)job.post_lo;
+    p.post_hi = (const T *)job.post_hi;
+    p.post_log_lo = job.post_log_lo;
+    p.has_post_const = job.has_post_const ? 1 : 0;
+    memcpy((void *)&p.post_const, (const void *)job.post_const, sizeof(T));
+
+    const uint64_t n = 1ull << L;
+    T *tmp = nullptr;
+    if (p.npass > 1) {
+        void *t;
+        WF_TRY(wf_scratch(ctx, 0, (size_t)n * job.nvec * sizeof(T), &t));
+        tmp = (T *)t;
+    }
+    for (uint32_t q = 0; q < p.npass; q++) {
+        const bool first = q == 0, last = q + 1 == p.npass;
+        p.pass = q;
+        if (first) {
+            p.src = (const T *)job.src;
+            p.src_div = job.src_div ? job.src_div : 1;
+            p.src_inner = job.src_inner ? job.src_inner : 1;
+            p.src_vec_stride = job.src_vec_stride;
+            p.src_inner_stride = job.src_inner_stride;
+            p.src_es = job.src_es;
+        } else {
+            p.src = tmp;
+            p.src_div = 1;
+            p.src_inner = 1;
+            p.src_vec_stride = n;
+            p.src_inner_stride = 1;
+            p.src_es = 1;
+        }
+        if (last) {
+            p.dst = (T *)job.dst;
+            p.dst_inner = job.dst_inner ? job.dst_inner : 1;
+            p.dst_vec_stride = job.dst_vec_stride;
+            p.dst_inner_stride = job.dst_inner_stride;
+            p.dst_es = job.dst_es;
+        } else {
+            p.dst = tmp;
+            p.dst_inner = 1;
+            p.dst_vec_stride = n;
+            p.dst_inner_stride = 1;
+            p.dst_es = 1;
+        }
+        const uint32_t r = p.log_r[q];
+        const uint32_t Tc = 256u >> log_b_for(r);
+        const uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
+        const uint64_t blocks = (total_cols + Tc - 1) / Tc;
+        if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+        auto k = kernel_for<F>(r, last);
+        wf_prof_begin(ctx, last ? "ntt_pass_last" : "ntt_pass");
+        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+    }
+    return WF_OK;
+}

@@ -1,311 +1,12 @@
-// f64 (Goldilocks) NTT engine for gfx950.
-//
-// Computes what the reference's math::fft computes (math/src/fft/mod.rs:85-386, serial.rs, concurrent.rs,
-// fft_inputs.rs:215-252): natural-order in, natural-order out DFTs over the 2^k-th roots of unity of the
-// f64 field, with optional coset scaling on the input (evaluate_poly_with_offset) or output
-// (interpolate_poly_with_offset).  The reference's recursive radix-2 butterflies + bit-reversal permute
-// are NOT mirrored: field arithmetic is exact, so any DFT algorithm yields the same canonical values.
-//
-// Algorithm: a transform of n = 2^L points is split into P = ceil(L/8) passes of radix R_p = 2^(r_p)
-// (r_p <= 8, decimation in frequency, most significant index digit first).  One pass =
-//   - each 256-thread workgroup owns a tile of R_p "rows" (stride S_p = n / (R_1..R_p)) x T "columns";
-//     a thread holds A = 2^LOG_A elements in registers and runs an A-point DFT whose internal twiddles
-//     are powers of omega_16 = 2^12 (shifts, no multiplies; omega_64 = 8 in this field, f64/mod.rs:258-267),
-//   - multiplies by omega_{R_p}^(k_a * b), exchanges through LDS (padded, conflict-free),
-//   - runs the B-point DFT, multiplies by the inter-pass twiddle omega_n^(...) from a two-level table,
-//   - stores.  Passes 1..P-1 store in place (tile rows at the same addresses, coalesced along the
-//     columns); the last pass runs along the contiguous axis and stores digit-reversed so that the
-//     result is in natural order (coalesced along the tile's columns, which are the low output digits).
-// The inverse transform is the forward transform with the output index negated (k -> -k mod n) and a
-// 1/n scale, so only forward tables exist.
-//
-// HBM traffic: P reads + P writes of the data (P = 3 at n = 2^24), see DESIGN.md.
-#include "gl64.cuh"
-#include "dft_regs.cuh"
-#include "wf_internal.h"
+// f64 instantiation of the NTT engine (math/src/field/f64).
+#include "ntt_engine.cuh"
 
-namespace {
+int wf_ntt_run_f64(wf_ctx *ctx, const NttJob &job) { return ntt_run<HostF64>(ctx, job); }
 
-struct PassParams {
-    const uint64_t *src;
-    uint64_t *dst;
-    uint32_t log_n;
-    uint32_t npass;
-    uint32_t pass;
-    uint32_t log_r[4];
-    uint32_t nvec;
-    uint32_t src_div, src_inner, dst_inner;
-    uint64_t src_vec_stride, dst_vec_stride;
-    uint64_t src_inner_stride, dst_inner_stride;
-    uint32_t src_es, dst_es;
-    uint32_t inverse;
-    // tables
-    const uint64_t *w_lo, *w_hi;
-    uint32_t w_log_lo;
-    const uint64_t *w256;
-    const uint64_t *pre_lo, *pre_hi;
-    uint32_t pre_log_lo, pre_mod;
-    uint64_t pre_lo_stride, pre_hi_stride;
-    const uint64_t *post_lo, *post_hi;
-    uint32_t post_log_lo;
-    uint64_t post_const;
-};
-
-#ifndef NTT_WAVES_PER_EU
-#define NTT_WAVES_ATTR
-#else
-#define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_WAVES_PER_EU, NTT_WAVES_PER_EU)))
-#endif
-
-template <int LOG_A, int LOG_B, bool LAST>
-__global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams p) {
-    constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
-    constexpr int T = 256 / B;          // tile columns
-    constexpr int G = A / B;            // B-point DFTs per thread in step 2
-    static_assert(B == 1 || G == 1 || G == 2, "A must be B or 2B");
-    // LDS exchange buffer: non-last [k_a][b][t] with padded k_a rows; last [k_a][t][b] with padded b rows
-    constexpr int ROW_NL = B * T + 16;
-    constexpr int ROW_L = B + 1;
-    constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * T * ROW_L : A * ROW_NL);
-    __shared__ uint64_t lds[LDS_ELEMS];
-
-    const int tid = threadIdx.x;
-    const uint32_t L = p.log_n;
-    const uint64_t n = 1ull << L;
-    const uint64_t ncols = n >> LOG_R;                     // columns per vector
-    const uint64_t total_cols = ncols * (uint64_t)p.nvec;  // joint (vector, column) space
-    const uint64_t cc0 = (uint64_t)blockIdx.x * T;
-
-    // log2 of this digit's stride S_p
-    uint32_t log_s = L;
-    for (uint32_t q = 0; q <= p.pass; q++) log_s -= p.log_r[q];
-    const uint32_t log_mult = L - log_s - LOG_R;           // n / n_p = R_1..R_{p-1}
-
-    // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
-    int b1, t1;
-    if (!LAST) { t1 = tid % T; b1 = tid / T; } else { b1 = tid % B; t1 = tid / B; }
-    uint64_t x[A];
-    {
-        const uint64_t cc = cc0 + t1;
-        const bool active = cc < total_cols;
-        const uint64_t v = active ? cc / ncols : 0;
-        const uint64_t c = active ? cc % ncols : 0;
-        uint64_t base;
-        if (!LAST) {
-            const uint64_t rem = c & ((1ull << log_s) - 1);
-            base = ((c >> log_s) << (log_s + LOG_R)) + rem;
-        } else {
-            base = 0;
-            uint64_t cr = c;
-            uint32_t ls = L;
-            for (uint32_t q = 0; q + 1 < p.npass; q++) {
-                ls -= p.log_r[q];
-                base += (cr & ((1ull << p.log_r[q]) - 1)) << ls;
-                cr >>= p.log_r[q];
-            }
-        }
-        const uint64_t vs = v / p.src_div;
-        const uint64_t *src = p.src + (vs / p.src_inner) * p.src_vec_stride + (vs % p.src_inner) * p.src_inner_stride;
-        if (active) {
-#pragma unroll
-            for (int a = 0; a < A; a++) {
-                const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                x[a] = src[j * p.src_es];
-            }
-            if (p.pre_lo != nullptr && p.pass == 0) {
-                const uint32_t u = (uint32_t)(v % p.pre_mod);
-                const uint64_t *plo = p.pre_lo + u * p.pre_lo_stride, *phi = p.pre_hi + u * p.pre_hi_stride;
-#pragma unroll
-                for (int a = 0; a < A; a++) {
-                    const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                    x[a] = gl::mul(x[a], series_at(plo, phi, p.pre_log_lo, j));
-                }
-            }
-        } else {
-#pragma unroll
-            for (int a = 0; a < A; a++) x[a] = 0;
-        }
-        dft_dif<LOG_A>(x);
-        if (B > 1) {
-            // intra-pass twiddle omega_R^(k_a * b) = omega_256^((k_a * b) << (8 - LOG_R)), then LDS exchange
-#pragma unroll
-            for (int i = 0; i < A; i++) {
-                const int ka = brev(i, LOG_A);
-                uint64_t val = x[i];
-                if (ka != 0) val = gl::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
-                if (!LAST) lds[ka * ROW_NL + b1 * T + t1] = val;
-                else lds[(ka * T + t1) * ROW_L + b1] = val;
-            }
-        }
+int wf_ntt_run(wf_ctx *ctx, const NttJob &job) {
+    switch (job.field) {
+        case WF_FIELD_F64: return wf_ntt_run_f64(ctx, job);
+        case WF_FIELD_F128: return wf_ntt_run_f128(ctx, job);
+        default: return WF_ERR_UNSUPPORTED;
     }
-
-    if (B > 1) __syncthreads();
-
-    // ---- step 2: B-point DFT(s) over the low half, inter-pass twiddle, store -----------------------
-    const int t2 = (B > 1) ? tid % T : t1;
-    const int q2 = (B > 1) ? tid / T : 0;
-    const uint64_t cc = cc0 + t2;
-    if (cc >= total_cols) return;
-    const uint64_t v = cc / ncols;
-    const uint64_t c = cc % ncols;
-    uint64_t *dst = p.dst + (v / p.dst_inner) * p.dst_vec_stride + (v % p.dst_inner) * p.dst_inner_stride;
-    const uint64_t rem = c & ((1ull << log_s) - 1);
-    const uint64_t base_nl = ((c >> log_s) << (log_s + LOG_R)) + rem;
-
-    auto emit = [&](uint64_t val, uint32_t kp) {
-        if (!LAST) {
-            if (kp != 0) {
-                const uint64_t e = ((uint64_t)kp * rem) << log_mult;
-                val = gl::mul(val, series_at(p.w_lo, p.w_hi, p.w_log_lo, e));
-            }
-            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val;
-        } else {
-            uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
-            if (p.inverse) k = (n - k) & (n - 1);
-            if (p.post_lo != nullptr) val = gl::mul(val, series_at(p.post_lo, p.post_hi, p.post_log_lo, k));
-            else if (p.post_const != 0) val = gl::mul(val, p.post_const);
-            dst[k * p.dst_es] = val;
-        }
-    };
-
-    if (B == 1) {
-#pragma unroll
-        for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
-    } else {
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            const int ka = q2 + B * g;
-            uint64_t y[B];
-#pragma unroll
-            for (int bb = 0; bb < B; bb++) {
-                if (!LAST) y[bb] = lds[ka * ROW_NL + bb * T + t2];
-                else y[bb] = lds[(ka * T + t2) * ROW_L + bb];
-            }
-            dft_dif<LOG_B>(y);
-#pragma unroll
-            for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
-        }
-    }
-}
-
-typedef void (*pass_fn)(PassParams);
-
-template <int LA, int LB>
-pass_fn pick(bool last) {
-    return last ? (pass_fn)ntt_pass<LA, LB, true> : (pass_fn)ntt_pass<LA, LB, false>;
-}
-
-pass_fn kernel_for(uint32_t r, bool last) {
-    switch (r) {
-        case 1: return pick<1, 0>(last);
-        case 2: return pick<1, 1>(last);
-        case 3: return pick<2, 1>(last);
-        case 4: return pick<2, 2>(last);
-        case 5: return pick<3, 2>(last);
-        case 6: return pick<3, 3>(last);
-        case 7: return pick<4, 3>(last);
-        default: return pick<4, 4>(last);
-    }
-}
-
-uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
-
-}  // namespace
-
-// Split L bits into passes of at most 8 bits, as evenly as possible (largest first).
-static void plan_passes(uint32_t L, uint32_t &npass, uint32_t log_r[4]) {
-    npass = (L + 7) / 8;
-    if (npass == 0) npass = 1;
-    uint32_t rem = L;
-    for (uint32_t q = 0; q < npass; q++) {
-        uint32_t left = npass - q;
-        uint32_t r = (rem + left - 1) / left;
-        log_r[q] = r;
-        rem -= r;
-    }
-    for (uint32_t q = npass; q < 4; q++) log_r[q] = 0;
-}
-
-int wf_ntt_f64_run(wf_ctx *ctx, const NttJob &job) {
-    const uint32_t L = job.log_n;
-    if (L == 0) {
-        // 1-point transform: copy (with scaling) — handled by callers; nothing to do in place
-        return WF_ERR_INVALID_ARG;
-    }
-    if (L > 32) return WF_ERR_DOMAIN_TOO_LARGE;
-    PassParams p{};
-    p.log_n = L;
-    plan_passes(L, p.npass, p.log_r);
-    p.nvec = job.nvec;
-    p.inverse = job.inverse ? 1 : 0;
-    SeriesTable om;
-    WF_TRY(wf_get_omega_table(ctx, L, &om));
-    p.w_lo = om.d_lo;
-    p.w_hi = om.d_hi;
-    p.w_log_lo = om.log_lo;
-    uint64_t *w256;
-    WF_TRY(wf_get_w256(ctx, &w256));
-    p.w256 = w256;
-    p.pre_lo = job.pre_lo;
-    p.pre_hi = job.pre_hi;
-    p.pre_log_lo = job.pre_log_lo;
-    p.pre_mod = job.pre_mod ? job.pre_mod : 1;
-    p.pre_lo_stride = job.pre_lo_stride;
-    p.pre_hi_stride = job.pre_hi_stride;
-    p.post_lo = job.post_lo;
-    p.post_hi = job.post_hi;
-    p.post_log_lo = job.post_log_lo;
-    p.post_const = job.post_const;
-
-    const uint64_t n = 1ull << L;
-    uint64_t *tmp = nullptr;
-    if (p.npass > 1) {
-        void *t;
-        WF_TRY(wf_scratch(ctx, 0, (size_t)n * job.nvec * sizeof(uint64_t), &t));
-        tmp = (uint64_t *)t;
-    }
-    for (uint32_t q = 0; q < p.npass; q++) {
-        const bool first = q == 0, last = q + 1 == p.npass;
-        p.pass = q;
-        // source addressing
-        if (first) {
-            p.src = job.src;
-            p.src_div = job.src_div ? job.src_div : 1;
-            p.src_inner = job.src_inner ? job.src_inner : 1;
-            p.src_vec_stride = job.src_vec_stride;
-            p.src_inner_stride = job.src_inner_stride;
-            p.src_es = job.src_es;
-        } else {
-            p.src = tmp;
-            p.src_div = 1;
-            p.src_inner = 1;
-            p.src_vec_stride = n;
-            p.src_inner_stride = 1;
-            p.src_es = 1;
-        }
-        if (last) {
-            p.dst = job.dst;
-            p.dst_inner = job.dst_inner ? job.dst_inner : 1;
-            p.dst_vec_stride = job.dst_vec_stride;
-            p.dst_inner_stride = job.dst_inner_stride;
-            p.dst_es = job.dst_es;
-        } else {
-            p.dst = tmp;
-            p.dst_inner = 1;
-            p.dst_vec_stride = n;
-            p.dst_inner_stride = 1;
-            p.dst_es = 1;
-        }
-        const uint32_t r = p.log_r[q];
-        const uint32_t T = 256u >> log_b_for(r);
-        const uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
-        const uint64_t blocks = (total_cols + T - 1) / T;
-        if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
-        pass_fn k = kernel_for(r, last);
-        wf_prof_begin(ctx, last ? "ntt_pass_last" : "ntt_pass");
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
-        wf_prof_end(ctx);
-        WF_HIP(hipGetLastError());
-    }
-    return WF_OK;
 }

@@ -1,0 +1,140 @@
+// Host-side construction + caching of the constant tables, generic over the field (HostF64 / HostF128).
+#pragma once
+#include <string.h>
+
+#include "fields.cuh"
+#include "wf_internal.h"
+
+template <class T>
+static inline void split128(T v, uint64_t &lo, uint64_t &hi) {
+    lo = (uint64_t)v;
+    if constexpr (sizeof(T) > 8) hi = (uint64_t)(v >> 64); else hi = 0;
+}
+
+template <class T>
+static int wf_upload(wf_ctx *ctx, const std::vector<T> &h, void **d) {
+    void *p;
+    WF_HIP(hipMalloc(&p, h.size() * sizeof(T)));
+    ctx->owned.push_back(p);
+    WF_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope in the caller
+    *d = p;
+    return WF_OK;
+}
+
+// series scale * base^i (canonical inputs), i < 2^log_len
+template <class HF>
+static int wf_get_series_table(wf_ctx *ctx, typename HF::T base, typename HF::T scale, uint32_t log_len, SeriesTable *out) {
+    typedef typename HF::T T;
+    uint64_t b0, b1, s0, s1;
+    split128(base, b0, b1);
+    split128(scale, s0, s1);
+    SeriesKey key(HF::Dev::ID, b0, b1, s0, s1, log_len);
+    auto it = ctx->series.find(key);
+    if (it == ctx->series.end()) {
+        SeriesTable t;
+        t.log_len = log_len;
+        t.log_lo = log_len < 12 ? log_len : 12;
+        const uint64_t nlo = 1ull << t.log_lo, nhi = 1ull << (log_len - t.log_lo);
+        std::vector<T> lo(nlo), hi(nhi);
+        T cur = HF::from_u64(1);
+        for (uint64_t i = 0; i < nlo; i++) {
+            lo[i] = HF::to_internal(cur);
+            cur = HF::mulmod(cur, base);
+        }
+        const T step = cur;
+        cur = scale;
+        for (uint64_t i = 0; i < nhi; i++) {
+            hi[i] = HF::to_internal(cur);
+            cur = HF::mulmod(cur, step);
+        }
+        WF_TRY(wf_upload(ctx, lo, &t.d_lo));
+        WF_TRY(wf_upload(ctx, hi, &t.d_hi));
+        it = ctx->series.emplace(key, t).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
+template <class HF>
+static int wf_get_omega_table(wf_ctx *ctx, uint32_t log_n, SeriesTable *out) {
+    return wf_get_series_table<HF>(ctx, HF::root_of_unity(log_n), HF::from_u64(1), log_n, out);
+}
+
+// omega_256^e, e < 256 and omega_16^j, j < 8
+template <class HF>
+static int wf_get_small_tables(wf_ctx *ctx, void **w256, void **w16) {
+    typedef typename HF::T T;
+    const int id = HF::Dev::ID;
+    if (!ctx->w256.count(id)) {
+        std::vector<T> h(256), g(8);
+        const T w = HF::root_of_unity(8);
+        T cur = HF::from_u64(1);
+        for (int i = 0; i < 256; i++) {
+            h[i] = HF::to_internal(cur);
+            if (i % 16 == 0 && i / 16 < 8) g[i / 16] = h[i];   // omega_16^j = omega_256^(16 j)
+            cur = HF::mulmod(cur, w);
+        }
+        void *p;
+        WF_TRY(wf_upload(ctx, h, &p));
+        ctx->w256[id] = p;
+        WF_TRY(wf_upload(ctx, g, &p));
+        ctx->w16[id] = p;
+    }
+    *w256 = ctx->w256[id];
+    *w16 = ctx->w16[id];
+    return WF_OK;
+}
+
+// LDE pre-scale tables: for coset u (rows u + b*m of the LDE), series (offset * g^u)^j, j < n, g = omega_{n*b}
+template <class HF>
+static int wf_get_lde_tables(wf_ctx *ctx, typename HF::T offset_canon, uint32_t log_n, uint32_t log_b, wf_ctx::LdeTables *out,
+                             uint64_t *lo_stride, uint64_t *hi_stride) {
+    typedef typename HF::T T;
+    const uint32_t log_lo = log_n < 12 ? log_n : 12;
+    const uint64_t nlo = 1ull << log_lo, nhi = 1ull << (log_n - log_lo);
+    *lo_stride = nlo;
+    *hi_stride = nhi;
+    uint64_t o0, o1;
+    split128(offset_canon, o0, o1);
+    auto key = std::make_tuple((int)HF::Dev::ID, o0, o1, log_n, log_b);
+    auto it = ctx->lde_tables.find(key);
+    if (it == ctx->lde_tables.end()) {
+        const uint32_t b = 1u << log_b;
+        const T g = HF::root_of_unity(log_n + log_b);
+        std::vector<T> lo(nlo * b), hi(nhi * b);
+        for (uint32_t u = 0; u < b; u++) {
+            const T base = HF::mulmod(offset_canon, HF::powmod(g, u));
+            T cur = HF::from_u64(1);
+            for (uint64_t i = 0; i < nlo; i++) {
+                lo[u * nlo + i] = HF::to_internal(cur);
+                cur = HF::mulmod(cur, base);
+            }
+            const T step = cur;
+            cur = HF::from_u64(1);
+            for (uint64_t i = 0; i < nhi; i++) {
+                hi[u * nhi + i] = HF::to_internal(cur);
+                cur = HF::mulmod(cur, step);
+            }
+        }
+        wf_ctx::LdeTables t;
+        t.log_lo = log_lo;
+        WF_TRY(wf_upload(ctx, lo, &t.d_lo));
+        WF_TRY(wf_upload(ctx, hi, &t.d_hi));
+        it = ctx->lde_tables.emplace(key, t).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
+// read one base-field element (internal form) from a host pointer -> canonical value; rejects non-canonical words and 0
+template <class HF>
+static int wf_load_offset(const void *h_offset, typename HF::T *canon) {
+    if (!h_offset) return WF_ERR_INVALID_ARG;
+    typename HF::T m;
+    memcpy((void *)&m, h_offset, sizeof(m));
+    if (!HF::valid_internal(m)) return WF_ERR_INVALID_ARG;
+    *canon = HF::from_internal(m);
+    if (*canon == 0) return WF_ERR_ZERO_OFFSET;
+    return WF_OK;
+}

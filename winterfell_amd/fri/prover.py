@@ -15,7 +15,8 @@ from ..math import fft, fields
 class FriOptions:
     """fri::FriOptions (fri/src/options.rs:13-93)."""
 
-    def __init__(self, blowup_factor, folding_factor, remainder_max_degree):
+    def __init__(self, blowup_factor, folding_factor, remainder_max_degree, field=fields.f64):
+        self.field = field
         assert blowup_factor & (blowup_factor - 1) == 0, "blowup factor must be a power of two"          # options.rs:33-36
         assert folding_factor in (2, 4, 8, 16), "folding factor %d is not supported" % folding_factor   # options.rs:37-44
         self.blowup_factor = blowup_factor
@@ -23,7 +24,7 @@ class FriOptions:
         self.remainder_max_degree = remainder_max_degree
 
     def domain_offset(self):
-        return fields.new(fields.GENERATOR)                 # options.rs:52-54: B::GENERATOR
+        return self.field.new(self.field.GENERATOR)          # options.rs:52-54: B::GENERATOR
 
     def num_fri_layers(self, domain_size):
         """options.rs:85-93"""
@@ -61,29 +62,29 @@ class FriProver:
     def build_layers(self, channel, evaluations):
         """mod.rs:179-199.  evaluations: len*D words (numpy or device tensor) over the LDE coset."""
         assert not self.layers, "a prior proof generation request has not been completed yet"
-        ctx, D, N = self.ctx, self.D, self.options.folding_factor
+        ctx, D, N, f = self.ctx, self.D, self.options.folding_factor, self.options.field
         ev = ctx.to_device(evaluations) if isinstance(evaluations, np.ndarray) else evaluations
         ev = ev.reshape(-1)
-        length = ev.numel() // D
+        length = ev.numel() // (D * f.W)
         assert length & (length - 1) == 0
-        off = ctypes.c_uint64(int(self.options.domain_offset()))
-        off_p = ctypes.cast(ctypes.byref(off), ctypes.c_void_p)
+        off = f.element_words(int(self.options.domain_offset()))
+        off_p = off.ctypes.data_as(ctypes.c_void_p)
         for _ in range(self.options.num_fri_layers(length)):
             log_len = length.bit_length() - 1
             rows = length // N
-            transposed = ctx.empty_u64(rows, N * D)
+            transposed = ctx.empty_u64(rows, N * D * f.W)
             leaves = ctx.empty_u8(rows, 32)
             nodes = ctx.empty_u8(rows, 32)
             root = np.empty(32, dtype=np.uint8)
             # build_layer (mod.rs:202-222): commit ...
-            ctx.call("wf_fri_layer_commit", self.hasher.HASH_ID, WF_FIELD_F64, D, ptr(ev), log_len, N, ptr(transposed), ptr(leaves),
+            ctx.call("wf_fri_layer_commit", self.hasher.HASH_ID, f.ID, D, ptr(ev), log_len, N, ptr(transposed), ptr(leaves),
                      ptr(nodes), root.ctypes.data_as(ctypes.c_void_p))
             channel.commit_fri_layer(root)
             # ... draw alpha, fold
             alpha = np.ascontiguousarray(channel.draw_fri_alpha(), dtype=np.uint64)
-            assert alpha.size == D
-            folded = ctx.empty_u64(rows * D)
-            ctx.call("wf_fri_apply_drp", WF_FIELD_F64, D, ptr(transposed), log_len, N, off_p, alpha.ctypes.data_as(ctypes.c_void_p),
+            assert alpha.size == D * f.W
+            folded = ctx.empty_u64(rows * D * f.W)
+            ctx.call("wf_fri_apply_drp", f.ID, D, ptr(transposed), log_len, N, off_p, alpha.ctypes.data_as(ctypes.c_void_p),
                      ptr(folded))
             self.layers.append(FriLayer(MerkleTree(self.hasher, leaves, nodes, ctx), transposed))
             ev, length = folded, rows
@@ -91,14 +92,14 @@ class FriProver:
 
     def _set_remainder(self, channel, ev, length):
         """mod.rs:230-239: interpolate over the coset, keep len/blowup coefficients in reverse order, commit to them."""
-        D = self.D
+        D, f = self.D, self.options.field
         if length > 1:
-            coeffs = fft.interpolate_poly_with_offset(ev.clone(), None, self.options.domain_offset(), ext_degree=D, ctx=self.ctx)
-            host = self.ctx.to_host(coeffs).reshape(length, D)
+            coeffs = fft.interpolate_poly_with_offset(ev.clone(), None, self.options.domain_offset(), ext_degree=D, ctx=self.ctx, field=f)
+            host = self.ctx.to_host(coeffs).reshape(length, D * f.W)
         else:
-            host = self.ctx.to_host(ev).reshape(1, D)
+            host = self.ctx.to_host(ev).reshape(1, D * f.W)
         size = length // self.options.blowup_factor
         rem = np.ascontiguousarray(host[:size][::-1])
-        commitment = self.hasher.hash_elements(rem.reshape(-1), self.ctx)
+        commitment = self.hasher.hash_elements(rem.reshape(-1), self.ctx, field=f)
         channel.commit_fri_layer(commitment)
         self.remainder_poly = rem

@@ -33,3 +33,47 @@ def to_ints(vals) -> np.ndarray:
     a = np.asarray(vals, dtype=np.uint64)
     out = (a.astype(object) * _RINV) % M
     return out.astype(np.uint64).reshape(a.shape)
+
+
+# ---- field descriptors (what the C ABI's `field` argument selects) --------------------------------------
+class Field:
+    """A base field of the reference: id for the C ABI, words (u64) per element, modulus, 2-adicity, generator."""
+
+    def __init__(self, wf_id, name, words, modulus, two_adicity, generator, montgomery, max_ext):
+        self.ID, self.name, self.W, self.M = wf_id, name, words, modulus
+        self.TWO_ADICITY, self.GENERATOR, self.montgomery, self.MAX_EXT = two_adicity, generator, montgomery, max_ext
+        self._r = (1 << 64) % modulus if montgomery else 1
+        self._rinv = pow(self._r, modulus - 2, modulus)
+
+    def new(self, value):
+        """BaseElement::new: canonical integer -> internal representation (python int)."""
+        return (value % self.M) * self._r % self.M
+
+    def as_int(self, inner):
+        return inner * self._rinv % self.M
+
+    def pack(self, inner_vals):
+        """python ints (internal form) -> uint64 array of W little-endian words per element."""
+        vals = [int(v) for v in np.asarray(inner_vals, dtype=object).reshape(-1)]
+        out = np.empty((len(vals), self.W), dtype=np.uint64)
+        for k in range(self.W):
+            out[:, k] = [(v >> (64 * k)) & 0xFFFFFFFFFFFFFFFF for v in vals]
+        return out.reshape(-1)
+
+    def unpack(self, arr):
+        a = np.ascontiguousarray(arr, dtype=np.uint64).reshape(-1, self.W)
+        return [sum(int(a[i, k]) << (64 * k) for k in range(self.W)) for i in range(a.shape[0])]
+
+    def from_ints(self, vals):
+        return self.pack([self.new(int(v)) for v in np.asarray(vals, dtype=object).reshape(-1)])
+
+    def to_ints(self, arr):
+        return [self.as_int(v) for v in self.unpack(arr)]
+
+    def element_words(self, inner):
+        """one element (internal form, python int) as a ctypes-ready uint64 array."""
+        return self.pack([inner])
+
+
+f64 = Field(0, "f64", 1, M, 32, 7, True, 3)                                    # math/src/field/f64/mod.rs
+f128 = Field(1, "f128", 2, 2**128 - 45 * 2**40 + 1, 40, 3, False, 2)           # math/src/field/f128/mod.rs:40,152,157

@@ -5,6 +5,7 @@ import numpy as np
 
 from .._lib import WF_FIELD_F64, default_context, load_library, ptr
 from ..crypto.merkle import MerkleTree
+from ..math import fields
 
 
 class PartitionOptions:
@@ -29,12 +30,13 @@ class ColMatrix:
     """Column-major matrix: `data` is a (num_cols, num_rows * ext_degree) device tensor (one contiguous column per row
     of the tensor).  ColMatrix::new asserts: at least one column, power-of-two length (col_matrix.rs:44-62)."""
 
-    def __init__(self, columns, ext_degree=1, ctx=None):
+    def __init__(self, columns, ext_degree=1, ctx=None, field=fields.f64):
         self.ctx = ctx or default_context()
         self.ext_degree = ext_degree
+        self.field = field
         data = self.ctx.to_device(columns) if isinstance(columns, np.ndarray) else columns
         assert data.dim() == 2 and data.shape[0] > 0, "a matrix must contain at least one column"
-        n = data.shape[1] // ext_degree
+        n = data.shape[1] // (ext_degree * field.W)
         assert n > 1 and n & (n - 1) == 0, "number of rows in a matrix must be a power of 2 greater than 1"
         self.data = data
 
@@ -45,14 +47,17 @@ class ColMatrix:
         return self.data.shape[0] * self.ext_degree
 
     def num_rows(self):
-        return self.data.shape[1] // self.ext_degree
+        return self.data.shape[1] // (self.ext_degree * self.field.W)
+
+    def col_stride(self):
+        return self.data.shape[1] // self.field.W      # in base elements
 
     def interpolate_columns(self):
         """ColMatrix::interpolate_columns (col_matrix.rs:192-202): returns a new matrix of coefficients."""
         out = self.data.clone()
         log_n = self.num_rows().bit_length() - 1
-        self.ctx.call("wf_interpolate_columns", WF_FIELD_F64, self.ext_degree, ptr(out), self.num_cols(), out.shape[1], log_n)
-        return ColMatrix(out, self.ext_degree, self.ctx)
+        self.ctx.call("wf_interpolate_columns", self.field.ID, self.ext_degree, ptr(out), self.num_cols(), self.col_stride(), log_n)
+        return ColMatrix(out, self.ext_degree, self.ctx, self.field)
 
     def to_host(self):
         return self.ctx.to_host(self.data)
@@ -62,8 +67,9 @@ class RowMatrix:
     """Row-major matrix (prover/src/matrix/row_matrix.rs:28-41): data[row * row_width + col], row_width =
     8 * ceil(base_cols / 8), only the first elements_per_row words of a row are meaningful."""
 
-    def __init__(self, data, row_width, elements_per_row, ext_degree, ctx):
+    def __init__(self, data, row_width, elements_per_row, ext_degree, ctx, field=fields.f64):
         self.data, self.row_width, self.elements_per_row, self.ext_degree, self.ctx = data, row_width, elements_per_row, ext_degree, ctx
+        self.field = field
 
     @classmethod
     def evaluate_polys_over(cls, polys: ColMatrix, blowup, domain_offset):
@@ -72,12 +78,13 @@ class RowMatrix:
         n = polys.num_rows()
         log_n, log_b = n.bit_length() - 1, blowup.bit_length() - 1
         assert blowup & (blowup - 1) == 0
+        f = polys.field
         rw = load_library().wf_row_width(polys.num_cols(), polys.ext_degree)
-        out = ctx.empty_u64(n * blowup, rw)
-        off = ctypes.c_uint64(int(domain_offset))
-        ctx.call("wf_evaluate_polys_over", WF_FIELD_F64, polys.ext_degree, ptr(polys.data), polys.num_cols(), polys.data.shape[1],
-                 log_n, log_b, ctypes.cast(ctypes.byref(off), ctypes.c_void_p), ptr(out))
-        return cls(out, rw, polys.num_base_cols(), polys.ext_degree, ctx)
+        out = ctx.empty_u64(n * blowup, rw * f.W)
+        off = f.element_words(int(domain_offset))
+        ctx.call("wf_evaluate_polys_over", f.ID, polys.ext_degree, ptr(polys.data), polys.num_cols(), polys.col_stride(),
+                 log_n, log_b, off.ctypes.data_as(ctypes.c_void_p), ptr(out))
+        return cls(out, rw, polys.num_base_cols(), polys.ext_degree, ctx, f)
 
     def num_rows(self):
         return self.data.shape[0]
@@ -87,20 +94,20 @@ class RowMatrix:
 
     def row(self, idx):
         assert idx < self.num_rows()
-        return self.ctx.to_host(self.data[idx, : self.elements_per_row])
+        return self.ctx.to_host(self.data[idx, : self.elements_per_row * self.field.W])
 
     def rows(self, positions):
         """Batch row fetch for TraceLde::query (wf_rows_fetch)."""
         pos = np.ascontiguousarray(positions, dtype=np.uint64)
-        out = np.empty((len(pos), self.elements_per_row), dtype=np.uint64)
-        self.ctx.call("wf_rows_fetch", ptr(self.data), self.row_width, self.elements_per_row, 8,
+        out = np.empty((len(pos), self.elements_per_row * self.field.W), dtype=np.uint64)
+        self.ctx.call("wf_rows_fetch", ptr(self.data), self.row_width, self.elements_per_row, 8 * self.field.W,
                       pos.ctypes.data_as(ctypes.c_void_p), len(pos), out.ctypes.data_as(ctypes.c_void_p))
         return out
 
     def hash_rows(self, hasher, partition_options=None):
         po = partition_options or PartitionOptions()
         leaves = self.ctx.empty_u8(self.num_rows(), 32)
-        self.ctx.call("wf_hash_rows", hasher.HASH_ID, WF_FIELD_F64, self.ext_degree, ptr(self.data), self.num_rows(), self.row_width,
+        self.ctx.call("wf_hash_rows", hasher.HASH_ID, self.field.ID, self.ext_degree, ptr(self.data), self.num_rows(), self.row_width,
                       self.elements_per_row, po.num_partitions, min(po.hash_rate, 255), ptr(leaves))
         return leaves
 

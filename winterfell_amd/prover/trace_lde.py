@@ -12,10 +12,10 @@ from .matrix import ColMatrix, PartitionOptions, RowMatrix
 class StarkDomain:
     """The part of prover::StarkDomain the LDE needs (prover/src/domain.rs:15-76): trace length, blowup, offset."""
 
-    def __init__(self, trace_length, blowup, offset=None):
+    def __init__(self, trace_length, blowup, offset=None, field=fields.f64):
         self.trace_length = trace_length
         self.blowup = blowup
-        self.offset = fields.new(fields.GENERATOR) if offset is None else offset   # domain offset = B::GENERATOR
+        self.offset = field.new(field.GENERATOR) if offset is None else offset   # domain offset = B::GENERATOR
 
     def lde_domain_size(self):
         return self.trace_length * self.blowup
@@ -29,24 +29,24 @@ def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partit
     trace_polys: ColMatrix).  One fused library call: interpolate -> coset LDE -> row hashes -> Merkle tree."""
     ctx = trace.ctx
     po = partition_options or PartitionOptions()
-    n, b, D = trace.num_rows(), domain.blowup, trace.ext_degree
+    n, b, D, f = trace.num_rows(), domain.blowup, trace.ext_degree, trace.field
     assert n == domain.trace_length
     log_n, log_b = n.bit_length() - 1, b.bit_length() - 1
     polys = trace.data.clone()
     rw = load_library().wf_row_width(trace.num_cols(), D)
     N = n * b
-    lde = ctx.empty_u64(N, rw)
+    lde = ctx.empty_u64(N, rw * f.W)
     leaves = ctx.empty_u8(N, 32)
     nodes = ctx.empty_u8(N, 32)
     root = np.empty(32, dtype=np.uint8)
-    off = ctypes.c_uint64(int(domain.offset))
-    ctx.call("wf_build_trace_commitment", hasher.HASH_ID, WF_FIELD_F64, D, ptr(polys), trace.num_cols(), polys.shape[1], log_n, log_b,
-             ctypes.cast(ctypes.byref(off), ctypes.c_void_p), po.num_partitions, min(po.hash_rate, 255), int(skip_interpolate),
+    off = f.element_words(int(domain.offset))
+    ctx.call("wf_build_trace_commitment", hasher.HASH_ID, f.ID, D, ptr(polys), trace.num_cols(), trace.col_stride(), log_n, log_b,
+             off.ctypes.data_as(ctypes.c_void_p), po.num_partitions, min(po.hash_rate, 255), int(skip_interpolate),
              ptr(lde), ptr(leaves), ptr(nodes), root.ctypes.data_as(ctypes.c_void_p))
-    trace_lde = RowMatrix(lde, rw, trace.num_base_cols(), D, ctx)
+    trace_lde = RowMatrix(lde, rw, trace.num_base_cols(), D, ctx, f)
     tree = MerkleTree(hasher, leaves, nodes, ctx)
     assert trace_lde.num_rows() == domain.lde_domain_size()
-    return trace_lde, tree, ColMatrix(polys, D, ctx)
+    return trace_lde, tree, ColMatrix(polys, D, ctx, f)
 
 
 class DefaultTraceLde:
