@@ -130,6 +130,12 @@ int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint64_t num_le
 /* Hasher::merge over `count` independent pairs (crypto/src/hash/mod.rs:31-50): out[i] = merge(in[2i], in[2i+1]). */
 int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t count, void *d_out);
 
+/* Hasher::merge_many over `count` independent groups of k digests (crypto/src/hash/mod.rs:31-50; blake/mod.rs:37-39,
+ * rescue/rp64_256/mod.rs:194-196): d_digests[count][k][32 B] -> d_out[count][32 B].  This is the second half of a
+ * partitioned row commitment (row_matrix.rs:204-223) and what each GPU runs on the partition digests it received
+ * from its peers when columns are sharded across devices. */
+int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_digests, uint64_t count, uint32_t k, void *d_out);
+
 /* ElementHasher::hash_elements over `count` independent rows (hash/mod.rs:56-64); same layout as wf_hash_rows
  * without partitions. */
 int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,

@@ -208,3 +208,32 @@ def test_full_size_lde_commit_properties(wf, oracle):
     leaf, proof = tree.prove(12345)
     crypto.MerkleTree.verify(crypto.Blake3_256, tree.root(), 12345, leaf, proof)
     assert not nodes[0].any()
+
+
+@pytest.mark.parametrize("hname,world", [("Blake3_256", 4), ("Rp64_256", 2), ("Blake3_256", 8)])
+def test_column_sharded_commitment_emulated_on_one_gpu(wf, oracle, hname, world):
+    """G logical column shards on one GPU (same kernels, same shard math as the multi-process path)
+    must reproduce the single-device commitment built with PartitionOptions(G, .) bit for bit."""
+    ctx, crypto, prover, fields = wf
+    from winterfell_amd import parallel
+    hasher = getattr(crypto, hname)
+    hid = _hid(crypto, hasher)
+    n, blowup, c = 1 << 9, 8, world * 4
+    trace = oracle.f64_from_int(rand_field(world, n * c)).reshape(c, n)
+    parts = parallel.column_partitions(c, world, 1, 1)
+    assert len(parts) == world
+    shards = [prover.ColMatrix(np.ascontiguousarray(trace[c0:c1])) for c0, c1 in parts]
+    res = parallel.emulated_sharded_commit(parallel.HipBackend(hasher, ctx), shards, prover.StarkDomain(n, blowup))
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(hid, trace, blowup, fields.new(7), num_partitions=world,
+                                                                      hash_rate=1, par=True)
+    N = n * blowup
+    per = N // world
+    for r, (leaves, nodes) in enumerate(res["per_rank"]):
+        assert np.array_equal(ctx.to_host(leaves), o_leaves[r * per:(r + 1) * per])
+    full = parallel.assemble_nodes(world, N, [ctx.to_host(nd) for _, nd in res["per_rank"]], ctx.to_host(res["top"]))
+    assert np.array_equal(full, o_nodes)
+    assert np.array_equal(ctx.to_host(res["root"]), o_nodes[1])
+    # and the single-device library call with the same PartitionOptions agrees too
+    _, tree, _ = prover.build_trace_commitment(hasher, prover.ColMatrix(trace), prover.StarkDomain(n, blowup),
+                                               prover.PartitionOptions(world, 1))
+    assert np.array_equal(tree.nodes, o_nodes)

@@ -288,6 +288,17 @@ extern "C" int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const vo
     return hash_rows_impl(ctx, hash, field, 1, d_elems, count, row_width, elems_per_row, 1, 1, d_out);
 }
 
+extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_digests, uint64_t count, uint32_t k, void *d_out) {
+    if (!ctx || !d_digests || !d_out || k == 0) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (count == 0) return WF_OK;
+    // Blake3: hash of the concatenated digest bytes (blake/mod.rs:37-39); Rp64_256: hash_elements over the 4*k digest
+    // elements (rp64_256/mod.rs:194-196).  Both are "raw words" for the row kernel.
+    return hash == WF_HASH_BLAKE3_256
+               ? launch_hash_rows<HBlake3>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out)
+               : launch_hash_rows<HRp64>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out);
+}
+
 extern "C" int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row,
                              uint32_t elem_bytes, const uint64_t *h_positions, uint32_t count, void *h_out) {
     if (!ctx || !d_rows || !h_positions || !h_out || (elem_bytes != 8 && elem_bytes != 16)) return WF_ERR_INVALID_ARG;
