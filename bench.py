@@ -101,6 +101,31 @@ def main():
                    "log_n": args.log_n, "step": "evaluate_poly + interpolate_poly", "parallelism": "dp%d" % world},
     }
 
+    # ---- N > 1 only: column-sharded trace LDE + commit (partition digests over RCCL all-to-all, sub-roots all-gather).
+    # Every rank owns 4 of the 4*N f64 columns of a 2^20-row trace; this is the one place the path has an exchange step.
+    sharded = None
+    if world > 1 and not args.no_extra:
+        try:
+            from winterfell_amd import parallel
+            tn, tb = 1 << 20, 8
+            shard = prover.ColMatrix(ctx.to_device(np.random.default_rng(7 + rank).integers(0, fields.M, (4, tn), dtype=np.uint64)))
+            dom = prover.StarkDomain(tn, tb)
+            backend = parallel.HipBackend(crypto.Blake3_256, ctx)
+            parallel.sharded_commit(backend, shard, dom)
+            barrier()
+            ts = []
+            for _ in range(5):
+                barrier()
+                t1 = time.perf_counter()
+                res = parallel.sharded_commit(backend, shard, dom)
+                barrier()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            tt = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded = {"sharded_lde_commit_ms_2^20x%d_b8_blake3" % (4 * world): float(tt.item())}
+        except Exception as e:  # never let the optional leg break the headline measurement
+            sharded = {"sharded_lde_commit_error": repr(e)[:200]}
+
     if rank == 0:
         # ---- roofline: per-kernel durations from HIP events on the launch stream (wf_prof_*) ----
         ctx.prof_enable(True)
@@ -140,6 +165,8 @@ def main():
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
                 ex["lde_commit_ms_2^20x4_b8_" + tag] = float(np.median(ts))
+            if sharded:
+                ex.update(sharded)
             out["extra"] = ex
 
         if not args.no_cpu_baseline:

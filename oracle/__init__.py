@@ -525,3 +525,15 @@ class GenericField:
 F128_M = 2**128 - 45 * 2**40 + 1
 f128 = GenericField("f128", 2, F128_M)
 f64t = GenericField("f64t", 1, M)
+F62_M = 4611624995532046337
+f62 = GenericField("f62", 1, F62_M)
+
+
+def f62_new(v):
+    lib().or_f62_new1.restype = _u64
+    return lib().or_f62_new1(_u64(v))
+
+
+def f62_as_int(v):
+    lib().or_f62_as_int1.restype = _u64
+    return lib().or_f62_as_int1(_u64(v))

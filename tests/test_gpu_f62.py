@@ -1,0 +1,94 @@
+"""GPU parity for the f62 base field (math/src/field/f62) and its quadratic / cubic extensions.  The reference keeps
+lazy Montgomery words in [0, 2M) and only observes them through normalize(); parity is on normalised words."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+M62 = 4611624995532046337
+
+
+def _rand62(oracle, seed, n):
+    rng = np.random.default_rng(seed)
+    v = rng.integers(0, M62, n, dtype=np.uint64)
+    return np.array([oracle.f62_new(int(x)) for x in v], dtype=np.uint64) if n <= 4096 else (v % M62)   # any value < M is a valid residue
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, fri, prover
+    from winterfell_amd.math import fft, fields
+    return winterfell_amd.default_context(), crypto, prover, fri, fft, fields
+
+
+@pytest.mark.parametrize("log_n", [1, 2, 4, 7, 8, 9, 12, 16, 17])
+def test_evaluate_interpolate_vs_oracle(wf, oracle, log_n):
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f62, oracle.f62
+    p = _rand62(oracle, log_n, 1 << log_n)
+    got = fft.evaluate_poly(p.copy(), field=f)
+    assert np.array_equal(got, of.evaluate_poly(p)), log_n
+    assert np.array_equal(fft.interpolate_poly(got.copy(), field=f), p)
+    assert np.array_equal(ctx.to_host(fft.get_twiddles(1 << log_n, field=f)), of.get_twiddles(1 << log_n))
+
+
+@pytest.mark.parametrize("D", [1, 2, 3])
+def test_offsets_and_extensions(wf, oracle, D):
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f62, oracle.f62
+    n = 1 << 10
+    p = _rand62(oracle, D, n * D)
+    off = f.new(3)
+    assert np.array_equal(fft.evaluate_poly(p.copy(), ext_degree=D, field=f), of.evaluate_poly(p, D))
+    assert np.array_equal(fft.evaluate_poly_with_offset(p, None, off, 8, ext_degree=D, field=f), of.evaluate_poly_with_offset(p, off, 8, D))
+    assert np.array_equal(fft.interpolate_poly_with_offset(p.copy(), None, off, ext_degree=D, field=f), of.interpolate_poly_with_offset(p, off, D))
+
+
+def test_lazy_words_are_accepted_and_normalised(wf, oracle):
+    """values in [M, 2M) (what the reference may hold in memory) give the same results as their normalised forms"""
+    ctx, _, _, _, fft, fields = wf
+    f, of = fields.f62, oracle.f62
+    p = _rand62(oracle, 5, 256)
+    lazy = p.copy()
+    lazy[::3] += np.uint64(M62)
+    assert np.array_equal(fft.evaluate_poly(lazy, field=f), of.evaluate_poly(p))
+
+
+@pytest.mark.parametrize("c,log_n,blowup,parts,D", [(4, 10, 8, 1, 1), (20, 8, 4, 4, 1), (3, 9, 8, 1, 3), (2, 9, 2, 1, 2)])
+def test_build_trace_commitment_vs_oracle(wf, oracle, c, log_n, blowup, parts, D):
+    ctx, crypto, prover, _, _, fields = wf
+    f, of = fields.f62, oracle.f62
+    n = 1 << log_n
+    trace = _rand62(oracle, c + log_n, n * c * D).reshape(c, n * D)
+    dom = prover.StarkDomain(n, blowup, field=f)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace, ext_degree=D, field=f), dom,
+                                                     prover.PartitionOptions(parts, 4))
+    o_polys, o_lde, o_leaves, o_nodes = of.build_trace_commitment(0, trace, blowup, f.new(3), D=D, num_partitions=parts, hash_rate=4)
+    assert np.array_equal(polys.to_host(), o_polys) and np.array_equal(lde.to_host(), o_lde)
+    assert np.array_equal(tree.leaves, o_leaves) and np.array_equal(tree.nodes, o_nodes)
+
+
+@pytest.mark.parametrize("D,N", [(1, 4), (3, 4), (2, 8)])
+def test_fri_layer_vs_oracle(wf, oracle, D, N):
+    ctx, crypto, _, fri, fft, fields = wf
+    from winterfell_amd._lib import ptr
+    f, of = fields.f62, oracle.f62
+    log_len, blowup = 11, 8
+    n = (1 << log_len) // blowup
+    ev = of.evaluate_poly_with_offset(_rand62(oracle, D * 10 + N, n * D), f.new(3), blowup, D)
+    rows = (1 << log_len) // N
+    tr, leaves, nodes = ctx.empty_u64(rows, N * D), ctx.empty_u8(rows, 32), ctx.empty_u8(rows, 32)
+    root = np.empty(32, dtype=np.uint8)
+    ctx.call("wf_fri_layer_commit", 0, f.ID, D, ptr(ctx.to_device(ev)), log_len, N, ptr(tr), ptr(leaves), ptr(nodes),
+             root.ctypes.data_as(ctypes.c_void_p))
+    o_tr = of.transpose_slice(ev, N, D)
+    o_leaves, o_nodes = of.fri_layer_commit(0, o_tr, N, D)
+    assert np.array_equal(ctx.to_host(nodes), o_nodes)
+    alpha = _rand62(oracle, 5, D)
+    off = f.element_words(f.new(3))
+    folded = ctx.empty_u64(rows * D)
+    ctx.call("wf_fri_apply_drp", f.ID, D, ptr(tr), log_len, N, off.ctypes.data_as(ctypes.c_void_p),
+             alpha.ctypes.data_as(ctypes.c_void_p), ptr(folded))
+    assert np.array_equal(ctx.to_host(folded), of.apply_drp(o_tr, N, f.new(3), alpha, D))

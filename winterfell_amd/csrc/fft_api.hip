@@ -222,45 +222,42 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
 
 }  // namespace
 
-#define WF_DISPATCH_FIELD(field, CALL_F64, CALL_F128) \
-    switch (field) {                                   \
-        case WF_FIELD_F64: return CALL_F64;            \
-        case WF_FIELD_F128: return CALL_F128;          \
-        default: return WF_ERR_UNSUPPORTED;            \
+#define WF_DISPATCH_FIELD(field, FN, ...)                          \
+    switch (field) {                                                \
+        case WF_FIELD_F64: return FN<HostF64>(__VA_ARGS__);         \
+        case WF_FIELD_F128: return FN<HostF128>(__VA_ARGS__);       \
+        case WF_FIELD_F62: return FN<HostF62>(__VA_ARGS__);         \
+        default: return WF_ERR_UNSUPPORTED;                         \
     }
 
 extern "C" int wf_fft_get_twiddles(wf_ctx *ctx, int field, uint32_t log_n, int inverse, void *d_out) {
     if (!ctx || !d_out || log_n == 0) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field, get_twiddles<HostF64>(ctx, log_n, inverse, d_out), get_twiddles<HostF128>(ctx, log_n, inverse, d_out));
+    WF_DISPATCH_FIELD(field, get_twiddles, ctx, log_n, inverse, d_out);
 }
 
 extern "C" int wf_fft_evaluate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_p, uint32_t log_n, uint32_t batch) {
     if (!ctx || !d_p || batch == 0) return WF_ERR_INVALID_ARG;
     const uint64_t cs = (uint64_t)ext_degree << log_n;
-    WF_DISPATCH_FIELD(field, fft_inplace_batch<HostF64>(ctx, ext_degree, d_p, log_n, batch, false, cs),
-                      fft_inplace_batch<HostF128>(ctx, ext_degree, d_p, log_n, batch, false, cs));
+    WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_p, log_n, batch, false, cs);
 }
 
 extern "C" int wf_fft_interpolate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
                                        uint32_t batch) {
     if (!ctx || !d_evals || batch == 0) return WF_ERR_INVALID_ARG;
     const uint64_t cs = (uint64_t)ext_degree << log_n;
-    WF_DISPATCH_FIELD(field, fft_inplace_batch<HostF64>(ctx, ext_degree, d_evals, log_n, batch, true, cs),
-                      fft_inplace_batch<HostF128>(ctx, ext_degree, d_evals, log_n, batch, true, cs));
+    WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_evals, log_n, batch, true, cs);
 }
 
 extern "C" int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_p, uint32_t log_n,
                                                 const void *h_offset, uint32_t log_blowup, void *d_result) {
     if (!ctx || !d_p || !d_result || log_n == 0) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field, evaluate_with_offset<HostF64>(ctx, ext_degree, d_p, log_n, h_offset, log_blowup, d_result),
-                      evaluate_with_offset<HostF128>(ctx, ext_degree, d_p, log_n, h_offset, log_blowup, d_result));
+    WF_DISPATCH_FIELD(field, evaluate_with_offset, ctx, ext_degree, d_p, log_n, h_offset, log_blowup, d_result);
 }
 
 extern "C" int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
                                                    const void *h_offset) {
     if (!ctx || !d_evals || log_n == 0) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field, interpolate_with_offset<HostF64>(ctx, ext_degree, d_evals, log_n, h_offset),
-                      interpolate_with_offset<HostF128>(ctx, ext_degree, d_evals, log_n, h_offset));
+    WF_DISPATCH_FIELD(field, interpolate_with_offset, ctx, ext_degree, d_evals, log_n, h_offset);
 }
 
 // ---- prover::matrix ---------------------------------------------------------------------------------
@@ -273,15 +270,12 @@ extern "C" int wf_interpolate_columns(wf_ctx *ctx, int field, uint32_t ext_degre
                                       uint64_t col_stride, uint32_t log_n) {
     if (!ctx || !d_cols || num_cols == 0) return WF_ERR_INVALID_ARG;
     if (col_stride < ((uint64_t)ext_degree << log_n)) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field, fft_inplace_batch<HostF64>(ctx, ext_degree, d_cols, log_n, num_cols, true, col_stride),
-                      fft_inplace_batch<HostF128>(ctx, ext_degree, d_cols, log_n, num_cols, true, col_stride));
+    WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_cols, log_n, num_cols, true, col_stride);
 }
 
 extern "C" int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
                                       uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
                                       void *d_lde) {
     if (!ctx || !d_polys || !d_lde || num_cols == 0 || log_n == 0) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field,
-                      evaluate_polys_over<HostF64>(ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde),
-                      evaluate_polys_over<HostF128>(ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde));
+    WF_DISPATCH_FIELD(field, evaluate_polys_over, ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde);
 }

@@ -19,6 +19,7 @@ struct F64 {
     static __device__ __forceinline__ T mul(T a, T b) { return gl::mul(a, b); }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
+    static __device__ __forceinline__ T load_norm(T a) { return a; }   // memory words are always canonical
     static __device__ __forceinline__ T mul_w16(T v, int j, const T *) {
         switch (j) {
             case 0: return v;
@@ -45,6 +46,7 @@ struct F128 {
     static __device__ __forceinline__ T mul(T a, T b) { return f128::mul(a, b); }
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
+    static __device__ __forceinline__ T load_norm(T a) { return a; }
     static __device__ __forceinline__ T mul_w16(T v, int j, const T *w16) { return j == 0 ? v : f128::mul(v, w16[j]); }
     // quadratic extension x^2 - x - 1 (f128/mod.rs:267-272)
     template <int D>
@@ -56,6 +58,58 @@ struct F128 {
             const T t = f128::mul(f128::add(a[0], a[1]), f128::add(b[0], b[1]));
             o[0] = f128::add(z, f128::mul(a[1], b[1]));
             o[1] = f128::sub(t, z);
+        }
+    }
+};
+
+// f62: p = 2^62 - 111*2^39 + 1, Montgomery residues (R = 2^64).  The reference keeps lazy values in [0, 2M)
+// (math/src/field/f62/mod.rs:61) and only ever observes them through normalize(); we keep every word normalised.
+namespace f62 {
+constexpr uint64_t M = 4611624995532046337ull;
+constexpr uint64_t U = 4611624995532046335ull;   // -M^-1 mod 2^64 (f62/mod.rs:48)
+__host__ __device__ __forceinline__ uint64_t norm(uint64_t v) { return v >= M ? v - M : v; }
+__host__ __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) { return norm(a + b); }
+__host__ __device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) { return a < b ? a + M - b : a - b; }
+__host__ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {   // f62/mod.rs:559-564, then normalize
+    const unsigned __int128 z = (unsigned __int128)a * b;
+    const uint64_t q = (uint64_t)z * U;
+    const unsigned __int128 r = z + (unsigned __int128)q * M;
+    return norm((uint64_t)(r >> 64));
+}
+}  // namespace f62
+
+struct F62 {
+    typedef uint64_t T;
+    static constexpr int ID = WF_FIELD_F62;
+    static constexpr int MAX_EXT = 3;
+    static constexpr bool SHIFT_TWIDDLES = false;
+    static __device__ __forceinline__ T add(T a, T b) { return f62::add(a, b); }
+    static __device__ __forceinline__ T sub(T a, T b) { return f62::sub(a, b); }
+    static __device__ __forceinline__ T mul(T a, T b) { return f62::mul(a, b); }
+    static __device__ __forceinline__ T zero() { return 0; }
+    static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
+    static __device__ __forceinline__ T load_norm(T a) { return f62::norm(a); }   // accept the reference's lazy [0, 2M) words
+    static __device__ __forceinline__ T mul_w16(T v, int j, const T *w16) { return j == 0 ? v : f62::mul(v, w16[j]); }
+    template <int D>
+    static __device__ __forceinline__ void ext_mul(const T (&a)[D], const T (&b)[D], T (&o)[D]) {
+        if constexpr (D == 1) {
+            o[0] = mul(a[0], b[0]);
+        } else if constexpr (D == 2) {   // x^2 - x - 1 (f62/mod.rs:321-326)
+            const T z = mul(a[0], b[0]);
+            const T t = mul(add(a[0], a[1]), add(b[0], b[1]));
+            o[0] = add(z, mul(a[1], b[1]));
+            o[1] = sub(t, z);
+        } else {                          // x^3 + 2x + 2 (f62/mod.rs:347-371)
+            const T a0b0 = mul(a[0], b[0]), a1b1 = mul(a[1], b[1]), a2b2 = mul(a[2], b[2]);
+            const T s01 = mul(add(a[0], a[1]), add(b[0], b[1]));
+            const T m02 = mul(sub(a[0], a[2]), sub(b[2], b[0]));
+            const T m12 = mul(sub(a[1], a[2]), sub(b[1], b[2]));
+            const T s = add(a0b0, a1b1);
+            const T u = sub(sub(m12, a1b1), a2b2);
+            const T t = add(u, u);
+            o[0] = add(a0b0, t);
+            o[1] = sub(sub(add(s01, t), add(a2b2, a2b2)), s);
+            o[2] = sub(add(m02, s), a2b2);
         }
     }
 };
@@ -90,4 +144,18 @@ struct HostF128 {
         const T G = ((T)0x120532e7b364080aull << 64) | 0x86b8723e1920f4aaull;   // f128/mod.rs:43
         return powmod(G, (unsigned __int128)1 << (40 - log_n));
     }
+};
+
+struct HostF62 {
+    typedef uint64_t T;
+    typedef F62 Dev;
+    static constexpr uint32_t TWO_ADICITY = 39;
+    static T mulmod(T a, T b) { return (T)(((unsigned __int128)a * b) % f62::M); }
+    static T from_u64(uint64_t v) { return v % f62::M; }
+    static T to_internal(T canon) { return (T)((((unsigned __int128)canon) << 64) % f62::M); }
+    static T powmod(T a, unsigned __int128 e) { T r = 1; while (e) { if (e & 1) r = mulmod(r, a); a = mulmod(a, a); e >>= 1; } return r; }
+    static T invmod(T a) { return powmod(a, (unsigned __int128)f62::M - 2); }
+    static T from_internal(T m) { return mulmod(m % f62::M, invmod(to_internal(1))); }
+    static bool valid_internal(T m) { return m < 2 * f62::M; }   // lazy words of the reference are accepted and normalised
+    static T root_of_unity(uint32_t log_n) { return powmod(4421547261963328785ull, (unsigned __int128)1 << (39 - log_n)); }   // f62/mod.rs:54
 };

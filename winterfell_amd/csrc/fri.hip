@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, t
 #pragma unroll
     for (int j = 0; j < N; j++)
 #pragma unroll
-        for (int d = 0; d < D; d++) comp[d][j] = t[(i * N + j) * D + d];
+        for (int d = 0; d < D; d++) comp[d][j] = F::load_norm(t[(i * N + j) * D + d]);
     // forward DFT per component (bit-reversed registers); inverse coefficient k = X[(N - k) mod N]
 #pragma unroll
     for (int d = 0; d < D; d++) dft_dif<F, LOG_NF>(comp[d], w16);
@@ -165,6 +165,7 @@ extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ex
     switch (field) {
         case WF_FIELD_F64: return layer_commit<HostF64>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
         case WF_FIELD_F128: return layer_commit<HostF128>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
+        case WF_FIELD_F62: return layer_commit<HostF62>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
         default: return WF_ERR_UNSUPPORTED;
     }
 }
@@ -175,6 +176,7 @@ extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, con
     switch (field) {
         case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
         case WF_FIELD_F128: return apply_drp<HostF128>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
+        case WF_FIELD_F62: return apply_drp<HostF62>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
         default: return WF_ERR_UNSUPPORTED;
     }
 }

@@ -9,13 +9,13 @@
 // Kernels: one row (or one row partition) per lane for leaf hashing; one workgroup per 1024-input subtree for the
 // tree (10 levels per launch, intermediate levels staged in LDS, every node written to the reference's heap layout).
 #include "blake3.cuh"
-#include "gl64.cuh"
+#include "fields.cuh"
 #include "rp64.cuh"
 #include "wf_internal.h"
 
 namespace {
 
-enum { MODE_F64_CANON = 0, MODE_RAW = 1 };
+enum { MODE_F64_CANON = 0, MODE_RAW = 1, MODE_F62_CANON = 2 };
 
 struct Digest {
     uint32_t w[8];
@@ -31,6 +31,12 @@ struct HBlake3 {
         if (mode == MODE_F64_CANON) {
             auto w = [&](uint32_t i) -> uint32_t {
                 const uint64_t v = gl::to_int(p[i >> 1]);
+                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+            };
+            b3::hash_words(w, nelem * 2, out);
+        } else if (mode == MODE_F62_CANON) {
+            auto w = [&](uint32_t i) -> uint32_t {
+                const uint64_t v = f62::mul(p[i >> 1] >= f62::M ? p[i >> 1] - f62::M : p[i >> 1], 1);   // as_int(): mont mul by 1
                 return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
             };
             b3::hash_words(w, nelem * 2, out);
@@ -237,13 +243,13 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
                           void *d_leaves) {
     if (!ctx || !d_rows || !d_leaves || num_rows == 0 || D == 0) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
-    if (field != WF_FIELD_F64 && field != WF_FIELD_F128) return WF_ERR_UNSUPPORTED;
-    if (field == WF_FIELD_F128 && hash == WF_HASH_RP64_256) return WF_ERR_UNSUPPORTED;   // Rp64_256 is defined over f64 only
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
+    if (field != WF_FIELD_F64 && hash == WF_HASH_RP64_256) return WF_ERR_UNSUPPORTED;   // Rp64_256 is defined over f64 only
     if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
     if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
     // f64 is not IS_CANONICAL: hash the canonical LE bytes; f128 is: hash the raw element bytes (blake/mod.rs:52-65).
     // Rows are addressed in 64-bit words: an f128 element is two words.
-    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : MODE_RAW;
+    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : (field == WF_FIELD_F62 ? MODE_F62_CANON : MODE_RAW);
     const uint32_t W = field == WF_FIELD_F128 ? 2 : 1;
     row_width *= W;
     elems_per_row *= W;

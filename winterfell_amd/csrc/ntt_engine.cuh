@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
 #pragma unroll
             for (int a = 0; a < A; a++) {
                 const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                x[a] = src[j * p.src_es];
+                x[a] = F::load_norm(src[j * p.src_es]);
             }
             if (p.pre_lo != nullptr && p.pass == 0) {
                 const uint32_t u = (uint32_t)(v % p.pre_mod);

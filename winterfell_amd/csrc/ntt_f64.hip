@@ -7,6 +7,7 @@ int wf_ntt_run(wf_ctx *ctx, const NttJob &job) {
     switch (job.field) {
         case WF_FIELD_F64: return wf_ntt_run_f64(ctx, job);
         case WF_FIELD_F128: return wf_ntt_run_f128(ctx, job);
+        case WF_FIELD_F62: return wf_ntt_run_f62(ctx, job);
         default: return WF_ERR_UNSUPPORTED;
     }
 }

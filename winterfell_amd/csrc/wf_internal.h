@@ -112,3 +112,4 @@ struct NttJob {
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field
 int wf_ntt_run_f64(wf_ctx *ctx, const NttJob &job);
 int wf_ntt_run_f128(wf_ctx *ctx, const NttJob &job);
+int wf_ntt_run_f62(wf_ctx *ctx, const NttJob &job);

@@ -77,3 +77,4 @@ class Field:
 
 f64 = Field(0, "f64", 1, M, 32, 7, True, 3)                                    # math/src/field/f64/mod.rs
 f128 = Field(1, "f128", 2, 2**128 - 45 * 2**40 + 1, 40, 3, False, 2)           # math/src/field/f128/mod.rs:40,152,157
+f62 = Field(2, "f62", 1, 4611624995532046337, 39, 3, True, 3)                  # math/src/field/f62/mod.rs:39,194
