@@ -237,3 +237,28 @@ def test_column_sharded_commitment_emulated_on_one_gpu(wf, oracle, hname, world)
     _, tree, _ = prover.build_trace_commitment(hasher, prover.ColMatrix(trace), prover.StarkDomain(n, blowup),
                                                prover.PartitionOptions(world, 1))
     assert np.array_equal(tree.nodes, o_nodes)
+
+
+@pytest.mark.parametrize("D,num_cols,ce_blowup", [(1, 2, 2), (2, 4, 4), (3, 8, 8), (1, 1, 2)])
+def test_constraint_commitment_vs_oracle(wf, oracle, D, num_cols, ce_blowup):
+    """build_constraint_commitment (prover/src/constraints/commitment/default.rs:109-150): CompositionPoly::new
+    (interpolate over the ce coset, segment) + LDE + commit, vs the oracle composed from its restated pieces."""
+    ctx, crypto, prover, fields = wf
+    n, blowup = 1 << 9, 8
+    ce_n = n * ce_blowup
+    comp_trace = oracle.f64_from_int(rand_field(D * 7 + num_cols, ce_n * D))
+    domain = prover.StarkDomain(n, blowup)
+    cc, poly = prover.build_constraint_commitment(crypto.Blake3_256, comp_trace.copy(), num_cols, domain, ext_degree=D)
+    coeffs = oracle.interpolate_poly_with_offset(comp_trace, fields.new(7), D=D)
+    cols = coeffs[: num_cols * n * D].reshape(num_cols, n * D)
+    assert np.array_equal(poly.data.to_host(), cols)
+    # polys -> LDE + commit (no interpolation): oracle pieces
+    o_lde = oracle.evaluate_polys_over(cols, blowup, fields.new(7), D=D)
+    o_leaves = oracle.hash_rows(0, o_lde, num_cols * D, D=D)
+    o_nodes = oracle.merkle_build(0, o_leaves)
+    assert np.array_equal(cc.evaluations.to_host(), o_lde)
+    assert np.array_equal(cc.vector_commitment.nodes, o_nodes) and np.array_equal(cc.commitment(), o_nodes[1])
+    rows, (leaves, proof) = cc.query([5, 100])
+    assert np.array_equal(rows, o_lde[[5, 100], : num_cols * D])
+    with pytest.raises(AssertionError, match="trace length must be smaller"):
+        prover.CompositionPoly.new(comp_trace[: n * D], domain, 1, ext_degree=D)
