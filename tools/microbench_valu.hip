@@ -47,6 +47,32 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint64_t seed) {
                 uint32_t lo = (uint32_t)x[i];
                 asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(lo) : "v"(b) : "vcc");
                 x[i] = lo;
+            } else if (OP == 10) {  // v_alignbit_b32 (rotate)
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_alignbit_b32 %0, %0, %0, 7" : "+v"(lo));
+                x[i] = lo;
+            } else if (OP == 11) {  // v_perm_b32 (byte rotate)
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_perm_b32 %0, %0, %0, %1" : "+v"(lo) : "v"(b));
+                x[i] = lo;
+            } else if (OP == 12) {  // v_add3_u32
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_add3_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));
+                x[i] = lo;
+            } else if (OP == 13) {  // v_xor_b32
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_xor_b32 %0, %0, %1" : "+v"(lo) : "v"(b));
+                x[i] = lo;
+            } else if (OP == 14) {  // v_xad_u32 (xor then add)
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_xad_u32 %0, %0, %1, %2" : "+v"(lo) : "v"(a), "v"(b));
+                x[i] = lo;
+            } else if (OP == 15) {  // v_mov_b32
+                uint32_t lo = (uint32_t)x[i];
+                asm volatile("v_mov_b32 %0, %1" : "=v"(lo) : "v"(lo));
+                x[i] = lo;
+            } else if (OP == 16) {  // v_lshlrev_b64
+                asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(x[i]));
             } else if (OP == 9) {  // v_cmp_lt_u64 + v_cndmask
                 uint32_t lo = (uint32_t)x[i];
                 asm volatile("v_cmp_lt_u64 vcc, %1, %2\n v_cndmask_b32 %0, %0, %3, vcc" : "+v"(lo) : "v"(x[i]), "v"(seed), "v"(b) : "vcc");
@@ -96,5 +122,12 @@ int main() {
     run<6>("v_add_co+v_addc_co", 2);
     run<8>("v_cndmask_b32", 1);
     run<9>("v_cmp_lt_u64+v_cndmask", 2);
+    run<10>("v_alignbit_b32", 1);
+    run<11>("v_perm_b32", 1);
+    run<12>("v_add3_u32", 1);
+    run<13>("v_xor_b32", 1);
+    run<14>("v_xad_u32", 1);
+    run<15>("v_mov_b32", 1);
+    run<16>("v_lshlrev_b64", 1);
     return 0;
 }

@@ -51,7 +51,17 @@ __device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
     return mont_red((uint64_t)x, (uint64_t)(x >> 64));
 }
 
-__device__ __forceinline__ uint64_t sqr(uint64_t a) { return mul(a, a); }
+// Montgomery square: the cross product a0*a1 is computed once (3 multiplies instead of 4)
+__device__ __forceinline__ uint64_t sqr(uint64_t a) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
+    const uint64_t p00 = (uint64_t)a0 * a0, p01 = (uint64_t)a0 * a1, p11 = (uint64_t)a1 * a1;
+    // a^2 = p00 + 2*p01*2^32 + p11*2^64
+    const uint64_t c2 = p01 >> 31;              // bits of 2*p01 above 2^32 position -> contributes to the high word
+    const uint64_t mid = p01 << 33;             // (2*p01 << 32) low 64 bits
+    const uint64_t lo = p00 + mid;
+    const uint64_t hi = p11 + c2 + (lo < p00);
+    return mont_red(lo, hi);
+}
 
 // canonical integer of an internal value (mont_to_int, f64/mod.rs:731-737)
 __device__ __forceinline__ uint64_t to_int(uint64_t a) { return mont_red(a, 0); }

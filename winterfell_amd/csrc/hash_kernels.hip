@@ -23,34 +23,29 @@ struct Digest {
 
 // ---- per-hasher primitives on 32-byte digests ----------------------------------------------------------------
 struct HBlake3 {
+    // levels reduced per Merkle launch: BLAKE3 merges are cheap, so a workgroup walks 10 levels through LDS
+    static constexpr uint32_t STAGE_LEVELS = 10;
     static const char *row_name() { return "hash_rows_blake3"; }
     static const char *merkle_name() { return "merkle_stage_blake3"; }
     static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) { b3::merge(in, out); }
-    // hash `nelem` 8-byte elements starting at p (stride 1); mode selects canonicalisation
-    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, int mode, uint32_t (&out)[8]) {
-        if (mode == MODE_F64_CANON) {
-            auto w = [&](uint32_t i) -> uint32_t {
-                const uint64_t v = gl::to_int(p[i >> 1]);
-                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
-            };
-            b3::hash_words(w, nelem * 2, out);
-        } else if (mode == MODE_F62_CANON) {
-            auto w = [&](uint32_t i) -> uint32_t {
-                const uint64_t v = f62::mul(p[i >> 1] >= f62::M ? p[i >> 1] - f62::M : p[i >> 1], 1);   // as_int(): mont mul by 1
-                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
-            };
-            b3::hash_words(w, nelem * 2, out);
-        } else {
-            auto w = [&](uint32_t i) -> uint32_t {
-                const uint64_t v = p[i >> 1];
-                return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
-            };
-            b3::hash_words(w, nelem * 2, out);
-        }
+    // hash `nelem` 64-bit words starting at p; MODE selects how a word is turned into message bytes
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
+        auto w = [&](uint32_t i) -> uint32_t {
+            uint64_t v = p[i >> 1];
+            if (MODE == MODE_F64_CANON) v = gl::to_int(v);                       // as_int(): canonical integer
+            else if (MODE == MODE_F62_CANON) v = f62::mul(f62::norm(v), 1);      // as_int(): Montgomery multiply by 1
+            return (i & 1) ? (uint32_t)(v >> 32) : (uint32_t)v;
+        };
+        if (MULTI) b3::hash_words(w, nelem * 2, out);
+        else b3::chunk(w, 0, nelem * 2, 0, true, out);                           // <= 1024 bytes: a single chunk, no CV stack
     }
 };
 
 struct HRp64 {
+    // a Rescue merge is ~6400 modmuls (0.2 ms of one wave): the nearly empty upper levels of a multi-level workgroup
+    // would serialise ten such latencies per workgroup, so the tree is built one full-width level per launch
+    static constexpr uint32_t STAGE_LEVELS = 1;
     static const char *row_name() { return "hash_rows_rp64"; }
     static const char *merkle_name() { return "merkle_stage_rp64"; }
     static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
@@ -64,7 +59,8 @@ struct HRp64 {
             out[2 * i + 1] = (uint32_t)(d[i] >> 32);
         }
     }
-    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, int mode, uint32_t (&out)[8]) {
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
         uint64_t d[4];
         auto e = [&](uint32_t i) -> uint64_t { return p[i]; };
         rp64::hash_elements(e, nelem, d);
@@ -94,20 +90,19 @@ __device__ __forceinline__ void load_pair(const void *src, uint64_t pair_idx, ui
     }
 }
 
-// leaf[r * parts + k] = H(elements [k*part_elems, min((k+1)*part_elems, elems_per_row)) of row r)
-template <class H>
+// leaf[r * parts + k] = H(words [k*part_words, min((k+1)*part_words, words_per_row)) of row r).  The partition index is
+// blockIdx.y, so the message length is uniform across a workgroup (scalar branches in the block loop).
+template <class H, int MODE, bool MULTI>
 __global__ __launch_bounds__(256) void hash_rows_kernel(const uint64_t *rows, uint64_t num_rows, uint64_t row_width,
-                                                        uint32_t elems_per_row, uint32_t part_elems, uint32_t parts,
-                                                        int mode, void *out) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid >= num_rows * parts) return;
-    const uint64_t r = gid / parts;
-    const uint32_t k = (uint32_t)(gid % parts);
+                                                        uint32_t elems_per_row, uint32_t part_elems, uint32_t parts, void *out) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= num_rows) return;
+    const uint32_t k = blockIdx.y;
     const uint32_t e0 = k * part_elems;
     const uint32_t e1 = (e0 + part_elems < elems_per_row) ? e0 + part_elems : elems_per_row;
     uint32_t d[8];
-    H::hash_elems(rows + r * row_width + e0, e1 - e0, mode, d);
-    store_digest(out, gid, d);
+    H::template hash_elems<MODE, MULTI>(rows + r * row_width + e0, e1 - e0, d);
+    store_digest(out, r * parts + k, d);
 }
 
 template <class H>
@@ -176,18 +171,33 @@ __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint
     reinterpret_cast<uint64_t *>(out)[gid] = reinterpret_cast<const uint64_t *>(rows + pos[r] * row_bytes)[w];
 }
 
-template <class H>
-int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
-                     uint32_t part_elems, uint32_t parts, int mode, void *out) {
-    const uint64_t total = num_rows * parts;
-    const uint64_t blocks = (total + 255) / 256;
-    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+template <class H, int MODE, bool MULTI>
+int launch_hash_rows_t(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
+                       uint32_t part_elems, uint32_t parts, void *out) {
+    const uint64_t blocks = (num_rows + 255) / 256;
+    if (blocks > 0x7fffffffull || parts > 65535) return WF_ERR_DOMAIN_TOO_LARGE;
     wf_prof_begin(ctx, H::row_name());
-    hipLaunchKernelGGL(hash_rows_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, rows, num_rows, row_width,
-                       elems_per_row, part_elems, parts, mode, out);
+    hipLaunchKernelGGL((hash_rows_kernel<H, MODE, MULTI>), dim3((uint32_t)blocks, parts), dim3(256), 0, ctx->stream, rows,
+                       num_rows, row_width, elems_per_row, part_elems, parts, out);
     wf_prof_end(ctx);
     WF_HIP(hipGetLastError());
     return WF_OK;
+}
+
+// all sizes in 64-bit words
+template <class H>
+int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
+                     uint32_t part_elems, uint32_t parts, int mode, void *out) {
+    const bool multi = part_elems > 128;   // more than one 1024-byte BLAKE3 chunk (ignored by Rescue)
+#define WF_HR(MODE)                                                                                                              \
+    return multi ? launch_hash_rows_t<H, MODE, true>(ctx, rows, num_rows, row_width, elems_per_row, part_elems, parts, out)       \
+                 : launch_hash_rows_t<H, MODE, false>(ctx, rows, num_rows, row_width, elems_per_row, part_elems, parts, out)
+    switch (mode) {
+        case MODE_F64_CANON: WF_HR(MODE_F64_CANON);
+        case MODE_F62_CANON: WF_HR(MODE_F62_CANON);
+        default: WF_HR(MODE_RAW);
+    }
+#undef WF_HR
 }
 
 template <class H>
@@ -196,8 +206,22 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
     const uint8_t *in = (const uint8_t *)leaves;
     uint64_t count = num_leaves;
     while (count > 1) {
+        if (H::STAGE_LEVELS == 1) {
+            // one level: nodes[count/2 + i] = merge(in[2i], in[2i+1]), one merge per lane
+            const uint64_t half = count >> 1;
+            const uint64_t blocks = (half + 255) / 256;
+            if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            wf_prof_begin(ctx, H::merkle_name());
+            hipLaunchKernelGGL(merge_batch_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, (const void *)in, half,
+                               (void *)((uint8_t *)nodes + half * 32));
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            count = half;
+            in = (const uint8_t *)nodes + count * 32;
+            continue;
+        }
         uint32_t log_ch = 0;
-        while ((1ull << log_ch) < count && log_ch < 10) log_ch++;
+        while ((1ull << log_ch) < count && log_ch < H::STAGE_LEVELS) log_ch++;
         const uint64_t wgs = count >> log_ch;
         if (wgs > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
         wf_prof_begin(ctx, H::merkle_name());
