@@ -139,9 +139,20 @@ def main():
         fwd_us = total_ms * 1e3 / reps
         alg_bytes = 2.0 * n * 8                         # read once + write once per transform
         achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
+        # HBM bytes per transform from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per the gfx950
+        # correction + WRITE_SIZE, summed over the transform's launches); only valid for the profiled size
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.json")) as f:
+                pm = json.load(f)["ntt_2^24_f64"]
+            if args.log_n == 24:
+                traffic = pm["hbm_bytes_per_transform"]
+        except Exception:
+            traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": None,
+            "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/r01/bench_pmc_summary.json)",
+            "limiter": "VALU issue (SQ_ACTIVE_INST_VALU ~ 90% of kernel time, see DESIGN.md section 5)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
