@@ -159,23 +159,58 @@ def main():
         }
 
         if not args.no_extra:
-            # ---- trace LDE + commit (second half of BASELINE's metric): 2^20 rows x 4 cols, blowup 8 ----
             ex = {}
-            for hname, tag in (("Blake3_256", "blake3"), ("Rp64_256", "rp64")):
-                hasher = getattr(crypto, hname)
-                tn, tc, tb = 1 << 20, 4, 8
-                tr = ctx.to_device(rng.integers(0, fields.M, (tc, tn), dtype=np.uint64))
-                cm = prover.ColMatrix(tr)
-                dom = prover.StarkDomain(tn, tb)
-                prover.build_trace_commitment(hasher, cm, dom)
+
+            def timed(fn, reps=5):
+                fn()
                 torch.cuda.synchronize()
                 ts = []
-                for _ in range(5):
+                for _ in range(reps):
                     t1 = time.perf_counter()
-                    prover.build_trace_commitment(hasher, cm, dom)
+                    fn()
                     torch.cuda.synchronize()
                     ts.append((time.perf_counter() - t1) * 1e3)
-                ex["lde_commit_ms_2^20x4_b8_" + tag] = float(np.median(ts))
+                return float(np.median(ts))
+
+            # ---- trace LDE + commit (second half of BASELINE's metric): 2^20 rows x 4 cols, blowup 8 (configs[2] shape) ----
+            tn, tc, tb = 1 << 20, 4, 8
+            for hname, tag in (("Blake3_256", "blake3"), ("Rp64_256", "rp64")):
+                hasher = getattr(crypto, hname)
+                cm = prover.ColMatrix(ctx.to_device(rng.integers(0, fields.M, (tc, tn), dtype=np.uint64)))
+                dom = prover.StarkDomain(tn, tb)
+                ex["lde_commit_ms_2^20x4_b8_f64_" + tag] = timed(lambda: prover.build_trace_commitment(hasher, cm, dom))
+            # examples::rescue as shipped (configs[2], SURVEY D2 variant 3a): f128, 4 columns, Blake3_256
+            f128 = fields.f128
+            tr128 = rng.integers(0, 1 << 62, (tc, tn * 2), dtype=np.uint64)      # words < 2^62 => every u128 < p
+            cm128 = prover.ColMatrix(ctx.to_device(tr128), field=f128)
+            dom128 = prover.StarkDomain(tn, tb, field=f128)
+            ex["lde_commit_ms_2^20x4_b8_f128_blake3"] = timed(lambda: prover.build_trace_commitment(crypto.Blake3_256, cm128, dom128), 3)
+            # Merkle leaves/s (BLAKE3, 2^23 leaves)
+            lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
+            ms = timed(lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))
+            ex["merkle_blake3_leaves_per_s_2^23"] = (1 << 23) / (ms * 1e-3)
+            del lv
+            # FRI commit phase (configs[4] shape): 2^24 LDE domain, f64 quadratic extension, folding 4, rem-deg 31
+            from winterfell_amd import fri as wfri
+
+            class _Chan:   # deterministic stand-in for the host Fiat-Shamir channel (alpha values do not affect timing)
+                def __init__(self):
+                    self.k = 0
+
+                def commit_fri_layer(self, root):
+                    self.k += 1
+
+                def draw_fri_alpha(self):
+                    return np.array([fields.new(12345 + self.k), fields.new(777 + self.k)], dtype=np.uint64)
+
+            ev = ctx.to_device(rng.integers(0, fields.M, (1 << 24) * 2, dtype=np.uint64))
+
+            def fri_run():
+                pr = wfri.FriProver(wfri.FriOptions(8, 4, 31), crypto.Blake3_256, ext_degree=2)
+                pr.build_layers(_Chan(), ev)
+
+            ex["fri_build_layers_ms_2^24_quad_fold4_blake3"] = timed(fri_run, 3)
+            del ev
             if sharded:
                 ex.update(sharded)
             out["extra"] = ex

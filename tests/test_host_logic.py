@@ -50,3 +50,29 @@ def test_merkle_openings_on_host_nodes(oracle, golden):
         tree.prove_batch([1, 1])
     with pytest.raises(MerkleTreeError, match="TooFewLeafIndexes"):
         tree.prove_batch([])
+
+
+def test_fri_options(oracle):
+    """fri/src/options.rs:85-93 num_fri_layers incl. SURVEY D4 (folding 4/2 land on 2^8, folding 8 on 2^6)."""
+    from winterfell_amd.fri import FriOptions
+    for fold, rem, size in ((4, 31, 1 << 24), (2, 31, 1 << 24), (8, 31, 1 << 24), (4, 255, 1 << 16), (16, 7, 1 << 12), (2, 0, 8)):
+        o = FriOptions(8, fold, rem)
+        assert o.num_fri_layers(size) == oracle.fri_num_layers(size, fold, 8, rem)
+    assert FriOptions(8, 4, 31).num_fri_layers(1 << 24) == 8 and FriOptions(8, 8, 31).num_fri_layers(1 << 24) == 6
+    with pytest.raises(AssertionError):
+        FriOptions(8, 3, 31)          # fri/src/options.rs:37-44
+    from winterfell_amd.math import fields
+    assert FriOptions(8, 4, 31).domain_offset() == fields.new(7)
+    assert FriOptions(8, 4, 31, field=fields.f128).domain_offset() == 3
+
+
+def test_field_descriptors():
+    from winterfell_amd.math import fields
+    assert fields.f64.M == 2**64 - 2**32 + 1 and fields.f128.M == 2**128 - 45 * 2**40 + 1 and fields.f62.M == 2**62 - 111 * 2**39 + 1
+    for f in (fields.f64, fields.f128, fields.f62):
+        assert (f.M - 1) % (1 << f.TWO_ADICITY) == 0 and (f.M - 1) // (1 << f.TWO_ADICITY) % 2 == 1
+        for v in (0, 1, 12345, f.M - 1):
+            assert f.as_int(f.new(v)) == v
+        assert f.unpack(f.pack([f.new(5), f.new(f.M - 2)])) == [f.new(5), f.new(f.M - 2)]
+    assert fields.f128.W == 2 and fields.f128.new(7) == 7          # canonical representation
+    assert fields.f62.new(1) == (1 << 64) % fields.f62.M            # Montgomery form
