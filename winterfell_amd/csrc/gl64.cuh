@@ -4,9 +4,12 @@
 // always in [0, p) (f64/mod.rs:60).  Because field arithmetic is exact, any correct implementation that
 // keeps results canonical reproduces the reference's memory image bit for bit.
 //
-// gfx950 notes: there is no 64-bit integer multiplier; a 64x64->128 product is four v_mad_u64_u32.
-// Montgomery reduction for this prime is shift/add only (eprint 2022/274, the same form the reference
-// uses in mont_red_cst, f64/mod.rs:714-724) so a modmul is 4 mads + ~14 full-rate VALU ops.
+// gfx950 notes (tools/microbench_valu.hip): there is no 64-bit integer multiplier (a 64x64->128 product is four
+// v_mad_u64_u32), 64-bit adds/compares and every 8-byte-encoded instruction issue at about half the rate of a plain
+// 32-bit VOP2, and a carry chain costs one instruction per limb.  The primitives are therefore written at the
+// 32-bit limb level with explicit carry chains (__builtin_addc / __builtin_subc map 1:1 onto v_add_co / v_addc_co /
+// v_sub_co / v_subb_co), which keeps each of them within one or two instructions of the minimum:
+//   sub 5, add 8, Montgomery reduction 8 (+ 4 mads for the product), multiplication by 2^S 13 instructions.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -14,105 +17,148 @@
 namespace gl {
 
 typedef unsigned __int128 u128;
+typedef uint32_t u32;
 
 constexpr uint64_t P = 0xffffffff00000001ull;
 constexpr uint64_t EPS = 0xffffffffull;  // 2^64 mod p = 2^32 - 1
 
-// a + b mod p for canonical a, b  (f64/mod.rs:319-324: a - (p - b))
-__device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) {
-    uint64_t t = P - b;
-    uint64_t x = a - t;
-    uint32_t adj = 0u - (uint32_t)(a < t);
-    return x - (uint64_t)adj;
+#ifndef GL_HD
+#define GL_HD __device__ __forceinline__
+#endif
+
+GL_HD uint64_t join(u32 lo, u32 hi) { return ((uint64_t)hi << 32) | lo; }
+
+// funnel shift: low 32 bits of ((hi:lo) >> s), 0 < s < 32
+GL_HD u32 funnel(u32 hi, u32 lo, int s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, s);
+#else
+    return (u32)((((uint64_t)hi << 32) | lo) >> s);
+#endif
+}
+
+// (hi:lo) - (borrow ? EPS : 0), i.e. "+ p" after a subtraction that wrapped below zero:
+// -EPS = +1 - 2^32  =>  lo += borrow (carry k), hi += k - borrow.
+GL_HD uint64_t fix_borrow(u32 lo, u32 hi, u32 borrow) {
+    u32 c3, c4;
+    const u32 m = 0u - borrow;                       // 0xFFFFFFFF when a borrow happened
+    const u32 rl = __builtin_subc(lo, m, 0u, &c3);   // lo + borrow; c3 = borrow & (lo != 0xFFFFFFFF)
+    const u32 rh = __builtin_subc(hi, 0u, c3, &c4);  // hi - borrow + carry = hi - c3
+    return join(rl, rh);
 }
 
 // a - b mod p for canonical a, b  (f64/mod.rs:339-343)
-__device__ __forceinline__ uint64_t sub(uint64_t a, uint64_t b) {
-    uint64_t x = a - b;
-    uint32_t adj = 0u - (uint32_t)(a < b);
-    return x - (uint64_t)adj;
+GL_HD uint64_t sub(uint64_t a, uint64_t b) {
+    u32 c1, c2;
+    const u32 dl = __builtin_subc((u32)a, (u32)b, 0u, &c1);
+    const u32 dh = __builtin_subc((u32)(a >> 32), (u32)(b >> 32), c1, &c2);
+    return fix_borrow(dl, dh, c2);
 }
 
-__device__ __forceinline__ uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+// a + b mod p for canonical a, b  (f64/mod.rs:319-324: a - (p - b); p - b = (1 - b_lo, 0xFFFFFFFF - b_hi - borrow))
+GL_HD uint64_t add(uint64_t a, uint64_t b) {
+    u32 c1, c2, c3, c4;
+    const u32 tl = __builtin_subc(1u, (u32)b, 0u, &c1);
+    const u32 th = __builtin_subc(0xffffffffu, (u32)(b >> 32), c1, &c2);
+    const u32 dl = __builtin_subc((u32)a, tl, 0u, &c3);
+    const u32 dh = __builtin_subc((u32)(a >> 32), th, c3, &c4);
+    return fix_borrow(dl, dh, c4);
+}
 
-// Montgomery reduction of a 128-bit value (xh:xl) < p * 2^64  ->  x / 2^64 mod p, canonical.
-__device__ __forceinline__ uint64_t mont_red(uint64_t xl, uint64_t xh) {
-    uint64_t a = xl + (xl << 32);
-    uint64_t e = a < xl;
-    uint64_t b = a - (a >> 32) - e;
-    uint64_t r = xh - b;
-    uint32_t adj = 0u - (uint32_t)(xh < b);
-    return r - (uint64_t)adj;
+GL_HD uint64_t neg(uint64_t a) { return a ? P - a : 0; }
+
+// Montgomery reduction of a 128-bit value (xh:xl) < p * 2^64  ->  x / 2^64 mod p, canonical
+// (the same shift/add form as mont_red_cst, f64/mod.rs:714-724, eprint 2022/274), 8 limb instructions:
+//   a = xl + (xl << 32) (carry e);  b = a - (a >> 32) - e;  r = xh - b (borrow c);  r -= c ? EPS : 0
+GL_HD uint64_t mont_red(uint64_t xl, uint64_t xh) {
+    u32 e, t, u, c1, c2;
+    const u32 a0 = (u32)xl;
+    const u32 a1 = __builtin_addc((u32)(xl >> 32), a0, 0u, &e);
+    const u32 b0 = __builtin_subc(a0, a1, e, &t);
+    const u32 b1 = __builtin_subc(a1, 0u, t, &u);
+    const u32 r0 = __builtin_subc((u32)xh, b0, 0u, &c1);
+    const u32 r1 = __builtin_subc((u32)(xh >> 32), b1, c1, &c2);
+    return fix_borrow(r0, r1, c2);
 }
 
 // Montgomery product: (aR)(bR)/R = abR  (f64/mod.rs:357-359)
-__device__ __forceinline__ uint64_t mul(uint64_t a, uint64_t b) {
-    u128 x = (u128)a * (u128)b;
+GL_HD uint64_t mul(uint64_t a, uint64_t b) {
+    const u128 x = (u128)a * (u128)b;
     return mont_red((uint64_t)x, (uint64_t)(x >> 64));
 }
 
-// Montgomery square: the cross product a0*a1 is computed once (3 multiplies instead of 4)
-__device__ __forceinline__ uint64_t sqr(uint64_t a) {
-    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32);
-    const uint64_t p00 = (uint64_t)a0 * a0, p01 = (uint64_t)a0 * a1, p11 = (uint64_t)a1 * a1;
-    // a^2 = p00 + 2*p01*2^32 + p11*2^64
-    const uint64_t c2 = p01 >> 31;              // bits of 2*p01 above 2^32 position -> contributes to the high word
-    const uint64_t mid = p01 << 33;             // (2*p01 << 32) low 64 bits
-    const uint64_t lo = p00 + mid;
-    const uint64_t hi = p11 + c2 + (lo < p00);
-    return mont_red(lo, hi);
-}
+GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
 
 // canonical integer of an internal value (mont_to_int, f64/mod.rs:731-737)
-__device__ __forceinline__ uint64_t to_int(uint64_t a) { return mont_red(a, 0); }
+GL_HD uint64_t to_int(uint64_t a) { return mont_red(a, 0); }
 
 // Plain (non-Montgomery) reduction of lo + mid*2^64 + hi*2^96 with mid < 2^32, hi < 2^63:
-// 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).  Result canonical.
-__device__ __forceinline__ uint64_t reduce160(uint64_t lo, uint32_t mid, uint64_t hi) {
+// 2^64 = 2^32 - 1 and 2^96 = -1 (mod p).  Result canonical.  (Used by the Rescue MDS layer.)
+GL_HD uint64_t reduce160(uint64_t lo, uint32_t mid, uint64_t hi) {
     uint64_t t = lo - hi;
     if (lo < hi) t -= EPS;  // + p (mod 2^64)
-    uint64_t m = ((uint64_t)mid << 32) - (uint64_t)mid;  // mid * (2^32 - 1)
+    const uint64_t m = ((uint64_t)mid << 32) - (uint64_t)mid;  // mid * (2^32 - 1)
     uint64_t r = t + m;
     if (r < t) r += EPS;  // wrapped past 2^64: 2^64 = EPS (cannot wrap twice)
     if (r >= P) r -= P;
     return r;
 }
 
-// x * 2^S mod p for a compile-time 0 < S < 96.  Multiplying a Montgomery residue by the plain integer
-// 2^S gives the Montgomery residue of x*2^S, so this is how the radix-16 butterflies apply the
+// V = A + B * 2^32 (mod p) for 64-bit W = (w1:w0) plus a small correction, made canonical:
+//   input: 64-bit value (h:l) in [0, 2^64) and an "overflow" bit o meaning +2^64 (= +EPS mod p).
+//   returns ((h:l) + o*EPS) mod p, canonical.  (h:l) + o*EPS < 2^64 is guaranteed by the callers.
+GL_HD uint64_t fold_carry_canon(u32 l, u32 h, u32 o) {
+    u32 c5, c6, c7, c8;
+    const u32 m = 0u - o;
+    const u32 l2 = __builtin_addc(l, m, 0u, &c5);       // + 0xFFFFFFFF * o
+    const u32 h2 = __builtin_addc(h, 0u, c5, &c6);
+    // canonicalise: v >= p  <=>  v + EPS wraps
+    const u32 l3 = __builtin_addc(l2, 0xffffffffu, 0u, &c7);
+    const u32 h3 = __builtin_addc(h2, 0u, c7, &c8);
+    return c8 ? join(l3, h3) : join(l2, h2);
+}
+
+// x * 2^S mod p for a compile-time 0 < S < 96, S not a multiple of 32.  Multiplying a Montgomery residue by the
+// plain integer 2^S gives the Montgomery residue of x*2^S, so this is how the radix-16 butterflies apply the
 // twiddles omega_16^j = 2^(12 j)  (omega_64 = 8, f64/mod.rs:17,258-267).
+// With w = 2^32 (w^2 = w - 1, w^3 = -1 mod p) and x * 2^(S mod 32) = y0 + y1 w + y2 w^2 (32-bit limbs, y2 < 2^r):
+//   S < 32:      V = (y0 - y2) + (y1 + y2) w
+//   32 < S < 64: V = (-y1 - y2) + (y0 + y1) w
+//   64 < S < 96: V = (-y0 - y1) + (y0 - y2) w
 template <int S>
-__device__ __forceinline__ uint64_t mul_pow2(uint64_t x) {
-    static_assert(S > 0 && S < 96, "shift out of range");
-    uint64_t lo, hi;
-    uint32_t mid;
-    if constexpr (S < 32) {
-        lo = x << S;
-        mid = (uint32_t)(x >> (64 - S));
-        hi = 0;
-    } else if constexpr (S == 32) {
-        lo = x << 32;
-        mid = (uint32_t)(x >> 32);
-        hi = 0;
-    } else if constexpr (S < 64) {
-        lo = x << S;
-        mid = (uint32_t)(x >> (64 - S));
-        hi = x >> (96 - S);
-    } else if constexpr (S == 64) {
-        lo = 0;
-        mid = (uint32_t)x;
-        hi = x >> 32;
+GL_HD uint64_t mul_pow2(uint64_t x) {
+    static_assert(S > 0 && S < 96 && (S % 32) != 0, "shift out of range");
+    constexpr int R = S % 32, Q = S / 32;
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32);
+    const u32 y0 = x0 << R;
+    const u32 y1 = funnel(x1, x0, 32 - R);
+    const u32 y2 = x1 >> (32 - R);
+    u32 b1, b2, c, k1, k2;
+    if constexpr (Q == 0) {
+        // (y1:y0) + y2 * EPS:  h = y1 + y2 (carry c);  l = y0 - y2 (borrow b1);  h -= b1 (borrow b2);  overflow = c ^ b2
+        const u32 h = __builtin_addc(y1, y2, 0u, &c);
+        const u32 l = __builtin_subc(y0, y2, 0u, &b1);
+        const u32 h2 = __builtin_subc(h, 0u, b1, &b2);
+        return fold_carry_canon(l, h2, c ^ b2);
+    } else if constexpr (Q == 1) {
+        // V = y0 * 2^32 + y1 * EPS - y2 can be slightly negative and needs two-sided corrections at limb level; the
+        // 64-bit formulation (lo + mid * 2^64 + hi * 2^96) measured faster for this class (tools/microbench_field.hip)
+        (void)y0; (void)y1; (void)y2; (void)b1; (void)b2; (void)c; (void)k1; (void)k2;
+        return reduce160(x << S, (uint32_t)(x >> (64 - S)), x >> (96 - S));
     } else {
-        lo = 0;
-        mid = (uint32_t)(x << (S - 64));
-        hi = x >> (96 - S);
+        // V = (y0 - y2) * 2^32 - (y0 + y1)  =  y0 * EPS - y1 - y2 * 2^32 :   (y0 : -y0) with borrow, minus (y2 : y1)
+        const u32 l0 = __builtin_subc(0u, y0, 0u, &b1);          // -y0
+        const u32 h0 = __builtin_subc(y0, 0u, b1, &b2);          // y0 - [y0 != 0]   (b2 = 0 always)
+        const u32 l = __builtin_subc(l0, y1, 0u, &k1);
+        const u32 h = __builtin_subc(h0, y2, k1, &k2);           // k2 = 1 means the value went negative
+        (void)b2; (void)c;
+        return fix_borrow(l, h, k2);
     }
-    return reduce160(lo, mid, hi);
 }
 
 // ---- extension fields (math/src/field/f64/mod.rs:401-499), elements are D consecutive base words ----------
 // quadratic extension x^2 - x + 2: 3 base multiplications
-__device__ __forceinline__ void ext2_mul(const uint64_t (&a)[2], const uint64_t (&b)[2], uint64_t (&o)[2]) {
+GL_HD void ext2_mul(const uint64_t (&a)[2], const uint64_t (&b)[2], uint64_t (&o)[2]) {
     const uint64_t a0b0 = mul(a[0], b[0]);
     const uint64_t a1b1 = mul(a[1], b[1]);
     const uint64_t t = mul(add(a[0], a[1]), add(b[0], b[1]));
@@ -120,7 +166,7 @@ __device__ __forceinline__ void ext2_mul(const uint64_t (&a)[2], const uint64_t 
     o[1] = sub(t, a0b0);
 }
 // cubic extension x^3 - x - 1: 6 base multiplications
-__device__ __forceinline__ void ext3_mul(const uint64_t (&a)[3], const uint64_t (&b)[3], uint64_t (&o)[3]) {
+GL_HD void ext3_mul(const uint64_t (&a)[3], const uint64_t (&b)[3], uint64_t (&o)[3]) {
     const uint64_t a0b0 = mul(a[0], b[0]), a1b1 = mul(a[1], b[1]), a2b2 = mul(a[2], b[2]);
     const uint64_t s01 = mul(add(a[0], a[1]), add(b[0], b[1]));
     const uint64_t s02 = mul(add(a[0], a[2]), add(b[0], b[2]));
@@ -131,7 +177,7 @@ __device__ __forceinline__ void ext3_mul(const uint64_t (&a)[3], const uint64_t 
     o[2] = sub(s02, m);
 }
 template <int D>
-__device__ __forceinline__ void ext_mul(const uint64_t (&a)[D], const uint64_t (&b)[D], uint64_t (&o)[D]) {
+GL_HD void ext_mul(const uint64_t (&a)[D], const uint64_t (&b)[D], uint64_t (&o)[D]) {
     if constexpr (D == 1) o[0] = mul(a[0], b[0]);
     else if constexpr (D == 2) ext2_mul(a, b, o);
     else ext3_mul(a, b, o);
