@@ -45,7 +45,8 @@ enum {
     WF_ERR_UNSUPPORTED = 5,          /* field / hash / extension degree combination not available         */
     WF_ERR_HIP = 6,                  /* a HIP runtime call failed; see wf_last_hip_error()                */
     WF_ERR_NO_DEVICE = 7,
-    WF_ERR_ZERO_OFFSET = 8           /* fft/mod.rs:185 "domain offset cannot be zero"                     */
+    WF_ERR_ZERO_OFFSET = 8,          /* fft/mod.rs:185 "domain offset cannot be zero"                     */
+    WF_ERR_NOT_FOUND = 9             /* prover/src/channel.rs:175 "nonce not found"                        */
 };
 
 /* ---- enums ----------------------------------------------------------------------------------------- */
@@ -135,6 +136,21 @@ int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t cou
  * partitioned row commitment (row_matrix.rs:204-223) and what each GPU runs on the partition digests it received
  * from its peers when columns are sharded across devices. */
 int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_digests, uint64_t count, uint32_t k, void *d_out);
+
+/* Hasher::merge_with_int for `count` consecutive integers (blake/mod.rs:41-46, rescue/rp64_256/mod.rs:198-219):
+ * d_out[i] = merge_with_int(seed, first_value + i).  h_seed: 32 digest bytes in the library's digest layout
+ * (Rp64_256: four internal-form words).  This is RandomCoin::next / check_leading_zeros' hash
+ * (crypto/src/random/default.rs:92-98,141-146) evaluated for a range of counters / nonces. */
+int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h_seed, uint64_t first_value, uint64_t count,
+                                 void *d_out);
+
+/* ProverChannel::grind_query_seed (prover/src/channel.rs:169-185): the smallest nonce in [first_nonce, max_nonce]
+ * with RandomCoin::check_leading_zeros(nonce) >= grinding_factor (random/default.rs:141-146: trailing zero bits of
+ * the first 8 bytes, read little-endian, of merge_with_int(seed, nonce)).  The reference's serial path starts at 1
+ * and returns the first hit, i.e. the minimum; so does this (its `concurrent` path may return any hit).
+ * WF_ERR_NOT_FOUND when no nonce in the range qualifies. */
+int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grinding_factor, uint64_t first_nonce,
+             uint64_t max_nonce, uint64_t *h_nonce);
 
 /* ElementHasher::hash_elements over `count` independent rows (hash/mod.rs:56-64); same layout as wf_hash_rows
  * without partitions. */

@@ -369,6 +369,28 @@ class RandomCoin:
         assert rc == 0
         return out
 
+    def seed(self):
+        out = np.empty(32, dtype=np.uint8)
+        lib().or_coin_seed(self._buf, _ptr(out))
+        return out
+
+    def check_leading_zeros(self, value):
+        lib().or_coin_check_leading_zeros.restype = ctypes.c_uint32
+        return int(lib().or_coin_check_leading_zeros(self._buf, _u64(value)))
+
+    def grind(self, grinding_factor, limit=1 << 40):
+        """ProverChannel::grind_query_seed, serial path (prover/src/channel.rs:169-175); 0 when nothing below limit."""
+        lib().or_coin_grind.restype = _u64
+        return int(lib().or_coin_grind(self._buf, ctypes.c_uint32(grinding_factor), _u64(limit)))
+
+    def draw_integers(self, num_values, domain_size, nonce):
+        assert domain_size & (domain_size - 1) == 0 and num_values < domain_size
+        out = np.empty(num_values, dtype=np.uint64)
+        lib().or_coin_draw_integers.restype = _u64
+        n = int(lib().or_coin_draw_integers(self._buf, _u64(num_values), _u64(domain_size), _u64(nonce), _ptr(out)))
+        assert n == num_values, "failed to draw enough integers"   # RandomCoinError::FailedToDrawIntegers
+        return out
+
 
 class ProverChannel:
     """fri::DefaultProverChannel (fri/src/prover/channel.rs:60-127): coin seeded with no elements."""

@@ -136,3 +136,44 @@ int or_coin_draw(or_coin *c, unsigned D, uint64_t *out) {
     return 1;
 }
 uint64_t or_coin_sizeof(void) { return sizeof(or_coin); }
+
+/* first 8 bytes of Digest::as_bytes(), little-endian */
+static uint64_t digest_head(int hasher, const uint8_t d[32]) {
+    uint8_t bytes[32];
+    uint64_t v;
+    if (hasher == 1) or_rp64_digest_as_bytes((const uint64_t *)d, bytes);
+    else memcpy(bytes, d, 32);
+    memcpy(&v, bytes, 8);
+    return v;
+}
+/* check_leading_zeros — random/default.rs:141-146: trailing_zeros of the little-endian head of
+ * merge_with_int(seed, value) */
+uint32_t or_coin_check_leading_zeros(const or_coin *c, uint64_t value) {
+    uint8_t d[32];
+    or_hash_merge_with_int(c->hasher, c->seed, value, d);
+    uint64_t h = digest_head(c->hasher, d);
+    return h ? (uint32_t)__builtin_ctzll(h) : 64u;
+}
+/* grind_query_seed, serial path — prover/src/channel.rs:169-185: first nonce >= 1 that passes; 0 = none below limit */
+uint64_t or_coin_grind(const or_coin *c, uint32_t grinding_factor, uint64_t limit) {
+    for (uint64_t nonce = 1; nonce < limit; nonce++)
+        if (or_coin_check_leading_zeros(c, nonce) >= grinding_factor) return nonce;
+    return 0;
+}
+/* draw_integers — random/default.rs:209-248: reseed with the nonce, then draw masked 8-byte heads until num_values
+ * were collected (at most 1000 draws); returns the number written (== num_values on success) */
+uint64_t or_coin_draw_integers(or_coin *c, uint64_t num_values, uint64_t domain_size, uint64_t nonce, uint64_t *out) {
+    uint8_t d[32];
+    or_hash_merge_with_int(c->hasher, c->seed, nonce, d);
+    memcpy(c->seed, d, 32);
+    c->counter = 0;
+    const uint64_t mask = domain_size - 1;
+    uint64_t n = 0;
+    for (int iter = 0; iter < 1000 && n < num_values; iter++) {
+        c->counter += 1;
+        or_hash_merge_with_int(c->hasher, c->seed, c->counter, d);
+        out[n++] = digest_head(c->hasher, d) & mask;
+    }
+    return n;
+}
+void or_coin_seed(const or_coin *c, uint8_t out[32]) { memcpy(out, c->seed, 32); }

@@ -52,6 +52,52 @@ def test_merkle_openings_on_host_nodes(oracle, golden):
         tree.prove_batch([])
 
 
+class _OracleHasher:
+    """Hasher shim over the oracle so the host-side proof walks can run without a GPU."""
+    def __init__(self, oracle, hid):
+        self.o, self.hid = oracle, hid
+
+    def merge(self, values, ctx=None):
+        v = np.ascontiguousarray(values).view(np.uint8).reshape(-1, 2, 32)
+        out = np.stack([self.o.merge(self.hid, pair) for pair in v])
+        return out[0] if np.asarray(values).size == 64 else out
+
+
+@pytest.mark.parametrize("hid", [0, 1])
+def test_batch_proof_get_root_and_verify_batch(oracle, hid):
+    """crypto/src/merkle/tests.rs:188-254 (verify_batch over many index sets) + proofs.rs get_root error paths."""
+    from winterfell_amd.crypto import MerkleTree, MerkleTreeError
+    from conftest import splitmix64
+    h = _OracleHasher(oracle, hid)
+    for log_n, seed in ((1, 1), (3, 2), (5, 3), (7, 4)):
+        n = 1 << log_n
+        lv = (splitmix64(seed, n * 4) >> np.uint64(2)).view(np.uint8).reshape(n, 32)   # valid f64 words for Rp64
+        tree = MerkleTree(h, None, None, None)
+        tree._leaves, tree._nodes = lv, oracle.merkle_build(hid, lv)
+        root = tree.root()
+        rng = np.random.default_rng(seed)
+        sets = [[0], [n - 1], list(range(n)), [0, n - 1]] + [sorted(rng.choice(n, size=rng.integers(1, n + 1), replace=False).tolist())
+                                                              for _ in range(12)]
+        sets.append(list(reversed(sets[-1])))                                       # unsorted index lists are allowed
+        for idx in sets:
+            leaves, proof = tree.prove_batch(idx)
+            assert MerkleTree.verify_batch(h, root, idx, leaves, proof) is None
+            assert np.array_equal(proof.get_root(h, idx, leaves), root)
+            if n > 2:
+                bad = [l.copy() for l in leaves]
+                bad[0][0] ^= 1
+                with pytest.raises(MerkleTreeError, match="InvalidProof"):
+                    MerkleTree.verify_batch(h, root, idx, bad, proof)
+        leaves, proof = tree.prove_batch([0])
+        with pytest.raises(MerkleTreeError, match="TooFewLeafIndexes"):
+            proof.get_root(h, [], leaves)
+        with pytest.raises(MerkleTreeError, match="Duplicate"):
+            proof.get_root(h, [0, 0], leaves + leaves)
+        if n > 2:
+            with pytest.raises(MerkleTreeError, match="InvalidProof"):
+                proof.get_root(h, [0, 2], leaves + leaves)                           # wrong number of proof chains
+
+
 def test_fri_options(oracle):
     """fri/src/options.rs:85-93 num_fri_layers incl. SURVEY D4 (folding 4/2 land on 2^8, folding 8 on 2^6)."""
     from winterfell_amd.fri import FriOptions

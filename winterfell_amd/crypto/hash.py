@@ -5,6 +5,8 @@ Digests are 32-byte rows: raw bytes for Blake3_256 (ByteDigest<32>), four Montgo
 batch on the GPU — they exist so tests can be written exactly like the reference's; bulk work goes through
 RowMatrix.hash_rows / MerkleTree.
 """
+import ctypes
+
 import numpy as np
 
 from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, default_context, ptr
@@ -44,6 +46,24 @@ class _Hasher:
         ctx.call("wf_hash_elements_batch", cls.HASH_ID, field.ID, ptr(d_in), rows.shape[0], width, take, ptr(d_out))
         out = ctx.to_host(d_out)
         return out[0] if e.ndim == 1 else out
+
+
+    @classmethod
+    def merge_with_int(cls, seed, value, count=None, ctx=None):
+        """Hasher::merge_with_int(seed, value) (crypto/src/hash/mod.rs:44-46); with `count`, the digests for
+        value, value+1, ..., value+count-1 as a (count, 32) array (RandomCoin::next for a run of counters)."""
+        ctx = ctx or default_context()
+        s = np.ascontiguousarray(seed).view(np.uint8).reshape(32)
+        n = 1 if count is None else int(count)
+        d_out = ctx.empty_u8(max(n, 1), 32)
+        ctx.call("wf_hash_merge_with_int_batch", cls.HASH_ID, s.ctypes.data_as(ctypes.c_void_p), int(value), n, ptr(d_out))
+        out = ctx.to_host(d_out)[:n]
+        return out[0] if count is None else out
+
+    @classmethod
+    def digest_as_bytes(cls, digest):
+        """Digest::as_bytes (ByteDigest: the bytes themselves, crypto/src/hash/mod.rs:83-101)."""
+        return np.ascontiguousarray(digest).view(np.uint8).tobytes()
 
 
 class Blake3_256(_Hasher):

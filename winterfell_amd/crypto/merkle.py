@@ -21,6 +21,59 @@ class BatchMerkleProof:
         self.nodes = nodes
         self.depth = depth
 
+    def get_root(self, hasher, indexes, leaves, ctx=None):
+        """proofs.rs:110-250: recompute the root from the opened leaves and the proof's sibling nodes.  The walk is
+        level by level over the set of known nodes; each level's merges run as one GPU batch."""
+        if len(indexes) == 0:
+            raise MerkleTreeError("TooFewLeafIndexes")
+        n = 1 << self.depth
+        pos = {}
+        for k, idx in enumerate(indexes):
+            if idx >= n:
+                raise MerkleTreeError("LeafIndexOutOfBounds(%d, %d)" % (n, idx))
+            pos[idx] = k
+        if len(pos) != len(indexes):
+            raise MerkleTreeError("DuplicateLeafIndex")
+        pairs = sorted({i - (i & 1) for i in indexes})
+        if len(pairs) != len(self.nodes) or len(leaves) < len(indexes):
+            raise MerkleTreeError("InvalidProof")
+        used = [0] * len(pairs)                       # next unread proof node per pair (proof_pointers)
+
+        def take(i):
+            if used[i] >= len(self.nodes[i]):
+                raise MerkleTreeError("InvalidProof")
+            used[i] += 1
+            return np.asarray(self.nodes[i][used[i] - 1])
+
+        batch = []
+        for i, p in enumerate(pairs):
+            l = np.asarray(leaves[pos[p]]) if p in pos else take(i)
+            r = np.asarray(leaves[pos[p + 1]]) if p + 1 in pos else take(i)
+            batch.append(np.stack([l.reshape(-1).view(np.uint8), r.reshape(-1).view(np.uint8)]))
+        vals = hasher.merge(np.stack(batch), ctx).reshape(len(pairs), 32)
+        cur = [(p + n) >> 1 for p in pairs]
+        for _ in range(1, self.depth):
+            known = {node: vals[k] for k, node in enumerate(cur)}
+            nxt, batch = [], []
+            k = 0
+            while k < len(cur):
+                node, sib = cur[k], cur[k] ^ 1
+                if k + 1 < len(cur) and cur[k + 1] == sib:
+                    other = known[sib]
+                    k += 1
+                else:
+                    # proof nodes are filed under the node's position in this level's list (as prove_batch wrote them)
+                    other = take(k).reshape(-1).view(np.uint8)
+                a, b = (known[node], other) if node & 1 == 0 else (other, known[node])
+                batch.append(np.stack([a, b]))
+                nxt.append(node >> 1)
+                k += 1
+            vals = hasher.merge(np.stack(batch), ctx).reshape(len(nxt), 32)
+            cur = nxt
+        if len(cur) != 1 or cur[0] != 1:
+            raise MerkleTreeError("InvalidProof")
+        return vals[0]
+
 
 class MerkleTree:
     def __init__(self, hasher, leaves_dev, nodes_dev, ctx):
@@ -125,6 +178,12 @@ class MerkleTree:
         return leaves, BatchMerkleProof(nodes, self.depth())
 
     # ---- verification (mod.rs:283-307) ----------------------------------------------------------------------
+    @staticmethod
+    def verify_batch(hasher, root, indexes, leaves, proof, ctx=None):
+        """MerkleTree::verify_batch (mod.rs:296-307): Ok(()) <=> returns None; raises InvalidProof otherwise."""
+        if not np.array_equal(proof.get_root(hasher, indexes, leaves, ctx), np.asarray(root).reshape(-1).view(np.uint8)):
+            raise MerkleTreeError("InvalidProof")
+
     @staticmethod
     def verify(hasher, root, index, leaf, proof, ctx=None):
         pair = [leaf, proof[0]] if index & 1 == 0 else [proof[0], leaf]

@@ -17,6 +17,7 @@ extern "C" const char *wf_strerror(int status) {
         case WF_ERR_HIP: return "HIP runtime error";
         case WF_ERR_NO_DEVICE: return "no such HIP device";
         case WF_ERR_ZERO_OFFSET: return "domain offset cannot be zero";
+        case WF_ERR_NOT_FOUND: return "nonce not found";
         default: return "unknown status";
     }
 }

@@ -104,18 +104,13 @@ GL_HD uint64_t reduce160(uint64_t lo, uint32_t mid, uint64_t hi) {
     return r;
 }
 
-// V = A + B * 2^32 (mod p) for 64-bit W = (w1:w0) plus a small correction, made canonical:
-//   input: 64-bit value (h:l) in [0, 2^64) and an "overflow" bit o meaning +2^64 (= +EPS mod p).
-//   returns ((h:l) + o*EPS) mod p, canonical.  (h:l) + o*EPS < 2^64 is guaranteed by the callers.
+// ((h:l) + o * 2^64) mod p, canonical, for a value below 2^64 + 2^57 (o = the 2^64 bit):  with w = (h:l) + EPS,
+// o = 1 means the answer is w (no wrap: (h:l) is small), o = 0 means (h:l) >= p  <=>  w wraps, and then again w.
 GL_HD uint64_t fold_carry_canon(u32 l, u32 h, u32 o) {
-    u32 c5, c6, c7, c8;
-    const u32 m = 0u - o;
-    const u32 l2 = __builtin_addc(l, m, 0u, &c5);       // + 0xFFFFFFFF * o
-    const u32 h2 = __builtin_addc(h, 0u, c5, &c6);
-    // canonicalise: v >= p  <=>  v + EPS wraps
-    const u32 l3 = __builtin_addc(l2, 0xffffffffu, 0u, &c7);
-    const u32 h3 = __builtin_addc(h2, 0u, c7, &c8);
-    return c8 ? join(l3, h3) : join(l2, h2);
+    u32 c7, c8;
+    const u32 l3 = __builtin_addc(l, 0xffffffffu, 0u, &c7);
+    const u32 h3 = __builtin_addc(h, 0u, c7, &c8);
+    return (o | c8) ? join(l3, h3) : join(l, h);
 }
 
 // x * 2^S mod p for a compile-time 0 < S < 96, S not a multiple of 32.  Multiplying a Montgomery residue by the
@@ -141,10 +136,18 @@ GL_HD uint64_t mul_pow2(uint64_t x) {
         const u32 h2 = __builtin_subc(h, 0u, b1, &b2);
         return fold_carry_canon(l, h2, c ^ b2);
     } else if constexpr (Q == 1) {
-        // V = y0 * 2^32 + y1 * EPS - y2 can be slightly negative and needs two-sided corrections at limb level; the
-        // 64-bit formulation (lo + mid * 2^64 + hi * 2^96) measured faster for this class (tools/microbench_field.hip)
-        (void)y0; (void)y1; (void)y2; (void)b1; (void)b2; (void)c; (void)k1; (void)k2;
-        return reduce160(x << S, (uint32_t)(x >> (64 - S)), x >> (96 - S));
+        // V = (y0 + y1) * 2^32 - y1 - y2.  With h = y0 + y1 (carry c, worth 2^64 = 2^32 - 1) and t = y1 + y2 + c
+        // (carry d):  V = (h + c - d) * 2^32 - t, and h + c - d always lies in [0, 2^32), so only the final
+        // 64-bit subtraction can go negative (by less than 2^33): one conditional + p.
+        const u32 h = __builtin_addc(y0, y1, 0u, &c);
+        const u32 u = __builtin_addc(y2, 0u, c, &k1);            // y2 < 2^R: no carry
+        const u32 t = __builtin_addc(y1, u, 0u, &k2);            // k2 = d
+        const u32 h1 = __builtin_subc(h, 0u, k2, &b1);
+        const u32 h2 = __builtin_addc(h1, 0u, c, &b2);           // (h + c - d) mod 2^32, exact
+        const u32 l = __builtin_subc(0u, t, 0u, &k1);
+        const u32 hh = __builtin_subc(h2, 0u, k1, &k2);          // k2 = 1 means the value went negative
+        (void)b1; (void)b2;
+        return fix_borrow(l, hh, k2);
     } else {
         // V = (y0 - y2) * 2^32 - (y0 + y1)  =  y0 * EPS - y1 - y2 * 2^32 :   (y0 : -y0) with borrow, minus (y2 : y1)
         const u32 l0 = __builtin_subc(0u, y0, 0u, &b1);          // -y0

@@ -8,6 +8,8 @@
 //
 // Kernels: one row (or one row partition) per lane for leaf hashing; one workgroup per 1024-input subtree for the
 // tree (10 levels per launch, intermediate levels staged in LDS, every node written to the reference's heap layout).
+#include <string.h>
+
 #include "blake3.cuh"
 #include "fields.cuh"
 #include "rp64.cuh"
@@ -28,6 +30,21 @@ struct HBlake3 {
     static const char *row_name() { return "hash_rows_blake3"; }
     static const char *merkle_name() { return "merkle_stage_blake3"; }
     static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) { b3::merge(in, out); }
+    // merge_with_int (blake/mod.rs:41-46): hash of the 40 bytes seed || value.to_le_bytes() — one block
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint32_t cv[8], m[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            cv[i] = b3::iv(i);
+            m[i] = seed[i];
+            m[8 + i] = 0;
+        }
+        m[8] = (uint32_t)value;
+        m[9] = (uint32_t)(value >> 32);
+        b3::compress(cv, m, 0, 40, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, out);
+    }
+    // first 8 digest bytes as a little-endian integer (random/default.rs:141-146)
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) { return (uint64_t)d[0] | ((uint64_t)d[1] << 32); }
     // hash `nelem` 64-bit words starting at p; MODE selects how a word is turned into message bytes
     template <int MODE, bool MULTI>
     static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
@@ -58,6 +75,32 @@ struct HRp64 {
             out[2 * i] = (uint32_t)d[i];
             out[2 * i + 1] = (uint32_t)(d[i] >> 32);
         }
+    }
+    // merge_with_int (rp64_256/mod.rs:198-219): seed in rate[0..4], value (split at the modulus) in rate[4..6],
+    // capacity[0] = number of elements absorbed
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint64_t st[12];
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) st[4 + i] = (uint64_t)seed[2 * i] | ((uint64_t)seed[2 * i + 1] << 32);
+        constexpr uint64_t R2 = 0xfffffffe00000001ull;                  // 2^128 mod p: BaseElement::new(v) = mont(v * R2)
+        st[8] = gl::mul(value >= gl::P ? value - gl::P : value, R2);
+        if (value < gl::P) st[0] = rp64::mont_small(5);
+        else {
+            st[9] = rp64::mont_small(1);                                // value / M = 1 for any u64 >= M
+            st[0] = rp64::mont_small(6);
+        }
+        rp64::permute(st);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)st[4 + i];
+            out[2 * i + 1] = (uint32_t)(st[4 + i] >> 32);
+        }
+    }
+    // ElementDigest::as_bytes starts with the canonical LE bytes of the first element (rp64_256/digest.rs)
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) {
+        return gl::to_int((uint64_t)d[0] | ((uint64_t)d[1] << 32));
     }
     template <int MODE, bool MULTI>
     static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
@@ -113,6 +156,35 @@ __global__ __launch_bounds__(256) void merge_batch_kernel(const void *pairs, uin
     load_pair(pairs, gid, m);
     H::merge(m, d);
     store_digest(out, gid, d);
+}
+
+struct Seed {
+    uint32_t w[8];
+};
+
+// digest[i] = merge_with_int(seed, first + i)
+template <class H>
+__global__ __launch_bounds__(256) void merge_with_int_kernel(Seed seed, uint64_t first, uint64_t count, void *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t d[8];
+    H::merge_with_int(seed.w, first + gid, d);
+    store_digest(out, gid, d);
+}
+
+// Proof-of-work search (prover/src/channel.rs:169-185): lanes test nonces first + gid; every nonce whose new seed has
+// >= `factor` trailing zero bits in its 8-byte head competes for the minimum, which is what the reference's serial
+// `find` returns.
+template <class H>
+__global__ __launch_bounds__(256) void grind_kernel(Seed seed, uint64_t first, uint64_t count, uint32_t factor,
+                                                    unsigned long long *best) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t d[8];
+    H::merge_with_int(seed.w, first + gid, d);
+    const uint64_t h = H::head(d);
+    const uint32_t tz = h ? (uint32_t)__builtin_ctzll(h) : 64u;
+    if (tz >= factor) atomicMin(best, (unsigned long long)(first + gid));
 }
 
 // One stage of the tree: `count` input digests (a power of two), each workgroup reduces a chunk of
@@ -327,6 +399,65 @@ extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_dig
     return hash == WF_HASH_BLAKE3_256
                ? launch_hash_rows<HBlake3>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out)
                : launch_hash_rows<HRp64>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out);
+}
+
+extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h_seed, uint64_t first_value, uint64_t count,
+                                           void *d_out) {
+    if (!ctx || !h_seed || !d_out) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (count == 0) return WF_OK;
+    if (first_value + count < first_value) return WF_ERR_INVALID_ARG;
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    Seed seed;
+    memcpy(seed.w, h_seed, 32);
+    if (hash == WF_HASH_BLAKE3_256)
+        hipLaunchKernelGGL(merge_with_int_kernel<HBlake3>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
+    else
+        hipLaunchKernelGGL(merge_with_int_kernel<HRp64>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grinding_factor, uint64_t first_nonce,
+                        uint64_t max_nonce, uint64_t *h_nonce) {
+    if (!ctx || !h_seed || !h_nonce || grinding_factor > 64 || first_nonce > max_nonce) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    Seed seed;
+    memcpy(seed.w, h_seed, 32);
+    void *tmp;
+    WF_TRY(wf_scratch(ctx, 2, 8, &tmp));
+    unsigned long long *d_best = (unsigned long long *)tmp;
+    // batch ~ twice the expected number of trials, within [2^16, 2^24] lanes per launch
+    uint32_t lg = grinding_factor + 1;
+    if (lg < 16) lg = 16;
+    if (lg > 24) lg = 24;
+    if (hash == WF_HASH_RP64_256 && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
+    const uint64_t batch = 1ull << lg;
+    uint64_t first = first_nonce;
+    for (;;) {
+        const uint64_t left = max_nonce - first;               // nonces first .. max_nonce inclusive = left + 1
+        const uint64_t count = left < batch - 1 ? left + 1 : batch;
+        WF_HIP(hipMemsetAsync(d_best, 0xff, 8, ctx->stream));
+        wf_prof_begin(ctx, hash == WF_HASH_BLAKE3_256 ? "grind_blake3" : "grind_rp64");
+        if (hash == WF_HASH_BLAKE3_256)
+            hipLaunchKernelGGL(grind_kernel<HBlake3>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, seed, first,
+                               count, grinding_factor, d_best);
+        else
+            hipLaunchKernelGGL(grind_kernel<HRp64>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, seed, first,
+                               count, grinding_factor, d_best);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+        unsigned long long best;
+        WF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
+        WF_HIP(hipStreamSynchronize(ctx->stream));
+        if (best != ~0ull) {
+            *h_nonce = best;
+            return WF_OK;
+        }
+        if (count == left + 1) return WF_ERR_NOT_FOUND;
+        first += count;
+    }
 }
 
 extern "C" int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row,
