@@ -176,6 +176,31 @@ int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_deg
 int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row, uint32_t elem_bytes,
                   const uint64_t *h_positions, uint32_t count, void *h_out);
 
+/* ---- prover::composer (DEEP composition) and out-of-domain frames ------------------------------------- */
+/* ColMatrix::evaluate_columns_at for one or more points (prover/src/matrix/col_matrix.rs; polynom::eval,
+ * math/src/polynom/mod.rs:55-61).  TracePolyTable::get_ood_frame (prover/src/trace/poly_table.rs:68-76) and
+ * CompositionPoly::get_ood_frame (prover/src/constraints/composition_poly.rs:101-108) are this call with the points
+ * {z, z*g}.  d_polys: num_cols columns of 2^log_n coefficients, col_stride words apart; a coefficient is
+ * poly_ext_degree (1 = base-field column, or ext_degree) words.  h_points: num_points elements of ext_degree words.
+ * h_out[num_points][num_cols] elements of ext_degree words (host memory; the call synchronises the stream). */
+int wf_polys_evaluate_at(wf_ctx *ctx, int field, uint32_t poly_ext_degree, uint32_t ext_degree, const void *d_polys,
+                         uint32_t num_cols, uint64_t col_stride, uint32_t log_n, const void *h_points,
+                         uint32_t num_points, void *h_out);
+
+/* DeepCompositionPoly::add_trace_polys (prover/src/composer/mod.rs:67-169): the coefficients of
+ *   sum_i cc_i * [ (T_i(x) - T_i(z)) / (x - z) + (T_i(x) - T_i(z*g)) / (x - z*g) ]
+ * over the main-segment polys (base field), the aux-segment polys and the composition-poly columns (both over the
+ * extension), g = generator of the trace domain.  The reference subtracts cc_i * T_i(z) from coefficient 0 and then
+ * runs syn_div_in_place (math/src/polynom/mod.rs:499-506), which drops the remainder: the out-of-domain values only
+ * affect that dropped remainder, so they are not inputs here (composer/mod.rs:200-210).
+ * h_cc_trace: num_main + num_aux coefficients, h_cc_constraints: num_quotient coefficients, h_z: one element; all of
+ * ext_degree words in internal form.  d_out: 2^log_n elements (degree 2^log_n - 2: the last one is zero).
+ * Feed d_out to wf_fft_evaluate_poly_with_offset for DeepCompositionPoly::evaluate (composer/mod.rs:174-181). */
+int wf_deep_compose(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_main_polys, uint32_t num_main,
+                    uint64_t main_stride, const void *d_aux_polys, uint32_t num_aux, uint64_t aux_stride,
+                    const void *d_quotient_polys, uint32_t num_quotient, uint64_t quotient_stride, uint32_t log_n,
+                    const void *h_z, const void *h_cc_trace, const void *h_cc_constraints, void *d_out);
+
 /* ---- fri::FriProver (commit phase) ------------------------------------------------------------------- */
 /* FriProver::build_layer, first half (fri/src/prover/mod.rs:202-211): transpose_slice::<E, N> (utils/core/src/lib.rs:
  * 166-183) into d_transposed (kept: it is the layer's `evaluations` used by query_layer, mod.rs:297-319), then

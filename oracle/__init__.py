@@ -543,6 +543,26 @@ class GenericField:
         self._fn("apply_drp")(_ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _ptr(po), _ptr(pa), _ptr(out))
         return out
 
+    # ---- DEEP composition (arrays are internal-form words; points / coefficients are flat arrays of D*W words) ----
+    def evaluate_columns_at(self, polys, c, x, D, pD=1):
+        """polys: c columns of n coefficients of degree pD; x: one degree-D element.  Returns (c, D*W) words."""
+        v, px = _u64arr(polys), _u64arr(x)
+        n = v.size // (c * pD * self.W)
+        out = np.empty((c, D * self.W), dtype=np.uint64)
+        self._fn("evaluate_columns_at")(_ptr(v), _u64(c), _u64(n), ctypes.c_uint(pD), _ptr(px), ctypes.c_uint(D), _ptr(out))
+        return out
+
+    def deep_compose(self, main, c_main, aux, c_aux, quot, c_q, n, D, z, cc_trace, cc_constraints, ood_t_cur, ood_t_next,
+                     ood_q_cur, ood_q_next):
+        """DeepCompositionPoly::add_trace_polys (prover/src/composer/mod.rs:67-169) -> n*D*W words."""
+        arrs = [_u64arr(a if a is not None else np.zeros(1, dtype=np.uint64))
+                for a in (main, aux, quot, z, cc_trace, cc_constraints, ood_t_cur, ood_t_next, ood_q_cur, ood_q_next)]
+        out = np.empty(n * D * self.W, dtype=np.uint64)
+        m, a, q, pz, cct, ccc, otc, otn, oqc, oqn = arrs
+        self._fn("deep_compose")(_ptr(m), _u64(c_main), _ptr(a), _u64(c_aux), _ptr(q), _u64(c_q), _u64(n), ctypes.c_uint(D),
+                                 _ptr(pz), _ptr(cct), _ptr(ccc), _ptr(otc), _ptr(otn), _ptr(oqc), _ptr(oqn), _ptr(out))
+        return out
+
 
 F128_M = 2**128 - 45 * 2**40 + 1
 f128 = GenericField("f128", 2, F128_M)

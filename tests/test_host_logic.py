@@ -122,3 +122,17 @@ def test_field_descriptors():
         assert f.unpack(f.pack([f.new(5), f.new(f.M - 2)])) == [f.new(5), f.new(f.M - 2)]
     assert fields.f128.W == 2 and fields.f128.new(7) == 7          # canonical representation
     assert fields.f62.new(1) == (1 << 64) % fields.f62.M            # Montgomery form
+
+
+def test_roots_of_unity_match_reference_constants(oracle):
+    """get_root_of_unity follows the reference's TWO_ADIC_ROOT_OF_UNITY constants (f64/mod.rs:267 — note that this is
+    NOT 7^((M-1)/2^32) —, f128/mod.rs:43, f62/mod.rs:54); the oracle restates the same constants independently."""
+    from winterfell_amd.math import fields
+    for f, o in ((fields.f64, oracle.f64t), (fields.f128, oracle.f128), (fields.f62, oracle.f62)):
+        for n in (1, 2, 5, 16, f.TWO_ADICITY):
+            w = f.get_root_of_unity(n)
+            assert f.new(w) == o.root_of_unity(n)
+            assert pow(w, 1 << n, f.M) == 1 and pow(w, 1 << (n - 1), f.M) == f.M - 1
+    assert fields.f64.get_root_of_unity(6) == 8                        # omega_64 = 8: the shift-twiddle fact the NTT uses
+    with pytest.raises(AssertionError):
+        fields.f64.get_root_of_unity(33)

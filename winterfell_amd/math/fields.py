@@ -39,11 +39,17 @@ def to_ints(vals) -> np.ndarray:
 class Field:
     """A base field of the reference: id for the C ABI, words (u64) per element, modulus, 2-adicity, generator."""
 
-    def __init__(self, wf_id, name, words, modulus, two_adicity, generator, montgomery, max_ext):
+    def __init__(self, wf_id, name, words, modulus, two_adicity, generator, montgomery, max_ext, two_adic_root):
         self.ID, self.name, self.W, self.M = wf_id, name, words, modulus
         self.TWO_ADICITY, self.GENERATOR, self.montgomery, self.MAX_EXT = two_adicity, generator, montgomery, max_ext
+        self.TWO_ADIC_ROOT_OF_UNITY = two_adic_root
         self._r = (1 << 64) % modulus if montgomery else 1
         self._rinv = pow(self._r, modulus - 2, modulus)
+
+    def get_root_of_unity(self, n):
+        """StarkField::get_root_of_unity(n) (math/src/field/traits.rs:262-268): canonical integer of the 2^n-th root."""
+        assert 0 < n <= self.TWO_ADICITY, "order cannot exceed 2^%d" % self.TWO_ADICITY
+        return pow(self.TWO_ADIC_ROOT_OF_UNITY, 1 << (self.TWO_ADICITY - n), self.M)
 
     def new(self, value):
         """BaseElement::new: canonical integer -> internal representation (python int)."""
@@ -75,6 +81,6 @@ class Field:
         return self.pack([inner])
 
 
-f64 = Field(0, "f64", 1, M, 32, 7, True, 3)                                    # math/src/field/f64/mod.rs
-f128 = Field(1, "f128", 2, 2**128 - 45 * 2**40 + 1, 40, 3, False, 2)           # math/src/field/f128/mod.rs:40,152,157
-f62 = Field(2, "f62", 1, 4611624995532046337, 39, 3, True, 3)                  # math/src/field/f62/mod.rs:39,194
+f64 = Field(0, "f64", 1, M, 32, 7, True, 3, 7277203076849721926)                                    # math/src/field/f64/mod.rs
+f128 = Field(1, "f128", 2, 2**128 - 45 * 2**40 + 1, 40, 3, False, 2, 0x120532e7b364080a86b8723e1920f4aa)           # math/src/field/f128/mod.rs:40,152,157
+f62 = Field(2, "f62", 1, 4611624995532046337, 39, 3, True, 3, 4421547261963328785)                  # math/src/field/f62/mod.rs:39,194
