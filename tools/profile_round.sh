@@ -1,0 +1,18 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun) from the repo root:  tools/profile_round.sh r01
+# Produces under gpurun_out/profiles/<round>/: the plain bench line, the rocprofv3 --kernel-trace --stats summary of the
+# same bench command, and the PMC summary (separate --pmc passes, no tracing options combined with them).
+set -u
+R=${1:-r01}
+OUT=gpurun_out/profiles/$R
+RAW=gpurun_out/prof_raw_$R
+mkdir -p "$OUT" "$RAW"
+export TMPDIR=/tmp
+python bench.py > "$OUT/bench_n1.json" 2> "$RAW/bench_n1.err"
+rocprofv3 --kernel-trace --stats -d "$RAW/kt" -o $R --output-format csv -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > "$OUT/bench_under_rocprof.log" 2>&1
+cp "$RAW/kt/${R}_kernel_stats.csv" "$OUT/bench_kernel_stats.csv"
+rocprofv3 --pmc FETCH_SIZE -d "$RAW/pmc_fetch" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$RAW/pmc_write" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$RAW/pmc_sq" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+python tools/summarize_pmc.py "$RAW" $R > "$OUT/bench_pmc_summary.json"
+cut -c1-400 "$OUT/bench_n1.json"
