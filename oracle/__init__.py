@@ -563,6 +563,59 @@ class GenericField:
                                  _ptr(pz), _ptr(cct), _ptr(ccc), _ptr(otc), _ptr(otn), _ptr(oqc), _ptr(oqn), _ptr(out))
         return out
 
+    # ---- constraint evaluation (constraints_tmpl.inc) -----------------------------------------------------------
+    AIR_FIB_SMALL, AIR_RESCUE = 0, 1
+    AIR_SHAPES = {0: (2, 2, 0, 0), 1: (4, 4, 9, 16)}      # width, transition constraints, periodic columns, cycle
+
+    def air_evaluate_transition(self, air, D, cur, nxt, periodic):
+        """Air::evaluate_transition over degree-D elements; cur / nxt: width*D*W words, periodic: num_periodic*D*W."""
+        w, nt, npc, _ = self.AIR_SHAPES[air]
+        c, n_, pv = _u64arr(cur), _u64arr(nxt), _u64arr(periodic if len(periodic) else np.zeros(1, dtype=np.uint64))
+        out = np.empty(nt * D * self.W, dtype=np.uint64)
+        fn = self._fn("air_evaluate_transition")
+        fn.restype = ctypes.c_int
+        assert fn(ctypes.c_int(air), ctypes.c_uint(D), _ptr(c), _ptr(n_), _ptr(pv), _ptr(out)) == 0
+        return out
+
+    def air_periodic_polys(self, air):
+        """Air::get_periodic_column_polys -> (num_periodic, cycle*W) words."""
+        _, _, npc, cyc = self.AIR_SHAPES[air]
+        out = np.empty((max(npc, 1), max(cyc, 1) * self.W), dtype=np.uint64)
+        fn = self._fn("air_periodic_polys")
+        fn.restype = ctypes.c_int
+        assert fn(ctypes.c_int(air), _ptr(out)) == 0
+        return out[:npc]
+
+    def evaluate_constraints(self, air, lde, row_width, n, lde_blowup, ce_blowup, offset, D, cc_t, assertions, cc_b):
+        """DefaultConstraintEvaluator::evaluate (single segment, single-value assertions).
+        lde: (n*lde_blowup, row_width*W) words; assertions: list of (column, step, value words); cc_t / cc_b: flat words.
+        Returns n*ce_blowup*D*W words (CompositionPolyTrace)."""
+        l, t, b = _u64arr(lde), _u64arr(cc_t), _u64arr(cc_b)
+        cols = np.array([a[0] for a in assertions], dtype=np.uint64)
+        steps = np.array([a[1] for a in assertions], dtype=np.uint64)
+        vals = np.concatenate([_u64arr(a[2]).reshape(-1) for a in assertions])
+        po = self.pack([offset])
+        out = np.empty(n * ce_blowup * D * self.W, dtype=np.uint64)
+        fn = self._fn("evaluate_constraints")
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.c_int(air), _ptr(l), _u64(row_width), _u64(n), _u64(lde_blowup), _u64(ce_blowup), _ptr(po), ctypes.c_uint(D),
+                _ptr(t), _u64(len(assertions)), _ptr(cols), _ptr(steps), _ptr(vals), _ptr(b), _ptr(out))
+        assert rc == 0
+        return out
+
+    def fib_small_build_trace(self, n):
+        out = np.empty((2, n * self.W), dtype=np.uint64)
+        self._fn("fib_small_build_trace")(_u64(n), _ptr(out))
+        return out
+
+    def rescue_build_trace(self, seed, iterations):
+        """f128 only: RescueProver::build_trace -> (4, 16*iterations*W) words."""
+        assert self.name == "f128"
+        out = np.empty((4, 16 * iterations * self.W), dtype=np.uint64)
+        ps = self.pack(seed)
+        self._fn("rescue_build_trace")(_ptr(ps), _u64(iterations), _ptr(out))
+        return out
+
 
 F128_M = 2**128 - 45 * 2**40 + 1
 f128 = GenericField("f128", 2, F128_M)

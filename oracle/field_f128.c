@@ -24,3 +24,33 @@ static inline void f128_hash_elems(int hasher, const u128 *e, uint64_t n, uint8_
 }
 #define F_HASH_ELEMS f128_hash_elems
 #include "field_tmpl.inc"
+
+/* ---- Rescue example AIR over f128 (examples/src/rescue) -------------------------------------------------------- */
+#define RESCUE_CONST static const
+#include "rescue_f128_constants.h"
+#define AIR_HAVE_RESCUE 1
+#define F_ONE ((u128)1)
+#include "constraints_tmpl.inc"
+
+/* rescue::apply_round — examples/src/rescue/rescue.rs:41-53 (sbox, MDS, first half of ARK; inverse sbox, MDS, second half) */
+static void rescue_apply_round(u128 *st, uint64_t step) {
+    const u128 *ark = RESCUE_ARK[step % 16];
+    for (int i = 0; i < 4; i++) st[i] = f128_exp(st[i], 3);
+    or_f128_rescue_mds(1, st, RESCUE_MDS);
+    for (int i = 0; i < 4; i++) st[i] = f128_add(st[i], ark[i]);
+    for (int i = 0; i < 4; i++) st[i] = f128_exp(st[i], RESCUE_INV_ALPHA);
+    or_f128_rescue_mds(1, st, RESCUE_MDS);
+    for (int i = 0; i < 4; i++) st[i] = f128_add(st[i], ark[4 + i]);
+}
+/* RescueProver::build_trace — examples/src/rescue/prover.rs:30-55 (TraceTable::fill: row i+1 = update(i, row i)).
+ * trace: 4 columns of n = iterations * 16 elements, column-major. */
+void or_f128_rescue_build_trace(const u128 seed[2], uint64_t iterations, u128 *trace) {
+    const uint64_t n = iterations * 16;
+    u128 st[4] = {seed[0], seed[1], 0, 0};
+    for (uint64_t step = 0;; step++) {
+        for (int c = 0; c < 4; c++) trace[c * n + step] = st[c];
+        if (step + 1 == n) break;
+        if (step % 16 < 14) rescue_apply_round(st, step);
+        else st[2] = st[3] = 0;
+    }
+}

@@ -1,6 +1,7 @@
 /* ORACLE — TEST INFRASTRUCTURE ONLY.  f62 instantiation of field_tmpl.inc (math/src/field/f62/mod.rs).
  * Results are normalised to [0, M) on every operation (the reference's lazy [0, 2M) words are only ever observed
  * through normalize(), see f62.h). */
+#include <stdlib.h>
 #include "f62.h"
 void or_blake3_hash(const uint8_t *in, uint64_t len, uint8_t out[32]);
 
@@ -38,6 +39,8 @@ static inline void f62_hash_elems(int hasher, const uint64_t *e, uint64_t n, uin
 }
 #define F_HASH_ELEMS f62_hash_elems
 #include "field_tmpl.inc"
+#define F_ONE f62n_new(1)
+#include "constraints_tmpl.inc"
 uint64_t or_f62_new1(uint64_t v) { return f62n_new(v); }
 uint64_t or_f62_as_int1(uint64_t v) { return f62_as_int(v); }
 uint64_t or_f62_lazy_mul1(uint64_t a, uint64_t b) { return f62_mul(a, b); }

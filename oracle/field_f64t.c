@@ -14,3 +14,5 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
 #define F_EXT_MUL f64_extD_mul
 #define F_HASH_ELEMS(h, e, n, d) or_hash_elements((h), (e), (n), (d))
 #include "field_tmpl.inc"
+#define F_ONE f64_new(1)
+#include "constraints_tmpl.inc"

@@ -1,0 +1,142 @@
+"""Oracle self-check for the constraint-evaluation restatement (prover/src/constraints/evaluator + evaluation_table).
+The reference ships no golden vectors for it, so the restated PROVER path (evaluate over the constraint-evaluation domain,
+divide by the divisors' evaluations, combine) is pinned against the VERIFIER's formula (verifier/src/evaluator.rs:16-89,
+verifier/src/lib.rs ood consistency check) evaluated at a random out-of-domain point with independent python code:
+    H(z) == sum_k cc_k C_k(z) / Z_t(z)  +  sum_groups sum_a cc_a (T_col(z) - value) / (z - g^step)
+plus the structural facts the prover asserts: the combined evaluations interpolate to a polynomial of degree
+< num_composition_columns * n (valid trace => exact divisibility), and a corrupted trace breaks that."""
+import numpy as np
+import pytest
+
+from test_oracle_deep import Ext
+
+
+def _setup(oracle, fname):
+    fld = {"f64": oracle.f64t, "f128": oracle.f128, "f62": oracle.f62}[fname]
+    gen = {"f64": 7, "f128": 3, "f62": 3}[fname]
+    new = {"f64": oracle.f64_new, "f128": lambda v: v, "f62": oracle.f62_new}[fname]
+    return fld, new(gen), new
+
+
+def _rand_e(fld, count, D, seed):
+    rng = np.random.default_rng(seed)
+    return [[int(rng.integers(1, 2**62)) * int(rng.integers(1, 2**62)) % fld.M for _ in range(D)] for _ in range(count)]
+
+
+def _case(oracle, fname, air, n, D, seed, corrupt=False):
+    fld, offset, new = _setup(oracle, fname)
+    W = fld.W
+    if air == fld.AIR_FIB_SMALL:
+        trace = fld.fib_small_build_trace(n)
+        ce_blowup, ncols = 2, 1
+        one = new(1)
+        res = fld.unpack(trace[1])[n - 1]
+        assertions = [(0, 0, one), (1, 0, one), (1, n - 1, res)]
+    else:
+        trace = fld.rescue_build_trace([42, 43], n // 16)
+        ce_blowup, ncols = 4, 3
+        t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
+        assertions = [(0, 0, t0[0]), (1, 0, t1[0]), (0, n - 1, t0[n - 1]), (1, n - 1, t1[n - 1])]
+    if corrupt:
+        trace = trace.copy()
+        trace[1, 5 * W] ^= np.uint64(1)
+    lde_blowup = 8
+    polys, lde, _, _ = fld.build_trace_commitment(0, trace, lde_blowup, offset)
+    width, nt, npc, cyc = fld.AIR_SHAPES[air]
+    cc_t, cc_b = _rand_e(fld, nt, D, seed), _rand_e(fld, len(assertions), D, seed + 1)
+    out = fld.evaluate_constraints(air, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D,
+                                   fld.pack(sum(cc_t, [])), [(c, s, fld.pack([v])) for c, s, v in assertions], fld.pack(sum(cc_b, [])))
+    return dict(fld=fld, offset=offset, new=new, polys=polys, out=out, n=n, D=D, ce_blowup=ce_blowup, ncols=ncols, cc_t=cc_t, cc_b=cc_b,
+                assertions=assertions, air=air, width=width, nt=nt, npc=npc, cyc=cyc)
+
+
+def _composition_coeffs(c):
+    fld, D = c["fld"], c["D"]
+    co = fld.interpolate_poly_with_offset(c["out"], c["offset"], D)          # CompositionPoly::new, composition_poly.rs:72-73
+    return np.asarray(co).reshape(c["n"] * c["ce_blowup"], D * fld.W)
+
+
+CASES = [("f64", 0, 16, 1), ("f64", 0, 64, 2), ("f64", 0, 32, 3), ("f62", 0, 16, 2), ("f128", 0, 16, 1),
+         ("f128", 1, 32, 1), ("f128", 1, 64, 2)]
+
+
+@pytest.mark.parametrize("fname,air,n,D", CASES)
+def test_prover_evaluation_matches_verifier_formula(oracle, fname, air, n, D):
+    c = _case(oracle, fname, air, n, D, 17 * n + D)
+    fld, new, E = c["fld"], c["new"], Ext(c["fld"], D)
+    co = _composition_coeffs(c)
+    # degree: num_constraint_composition_columns * n coefficients at most (context.rs:265-285; composition_poly.rs:75-78)
+    assert not co[c["ncols"] * n:].any()
+    assert co[(c["ncols"] - 1) * n:c["ncols"] * n].any()
+    rng = np.random.default_rng(5)
+    z = [int(rng.integers(1, 2**62)) % fld.M for _ in range(D)]
+    g = fld.root_of_unity(n.bit_length() - 1)
+    zg = E.mul(z, E.lift(g))
+    zw, zgw = fld.pack(z), fld.pack(zg)
+    cur = fld.evaluate_columns_at(c["polys"], c["width"], zw, D, 1)           # ood main frame (verifier reads it from the proof)
+    nxt = fld.evaluate_columns_at(c["polys"], c["width"], zgw, D, 1)
+    # periodic values at z: poly(z^(n / cycle)), verifier/src/evaluator.rs:27-35
+    per = np.zeros(0, dtype=np.uint64)
+    if c["npc"]:
+        zc = E.lift(new(1))
+        for _ in range(n // c["cyc"]):
+            zc = E.mul(zc, z)
+        per = fld.evaluate_columns_at(fld.air_periodic_polys(c["air"]), c["npc"], fld.pack(zc), D, 1).reshape(-1)
+    tev = fld.unpack(fld.air_evaluate_transition(c["air"], D, cur.reshape(-1), nxt.reshape(-1), per))
+    T = [0] * D
+    for k in range(c["nt"]):
+        T = E.add(T, E.mul(c["cc_t"][k], tev[k * D:(k + 1) * D]))
+    zn = E.lift(new(1))
+    for _ in range(n):
+        zn = E.mul(zn, z)
+    num_t = E.sub(zn, E.lift(new(1)))                                         # x^n - 1
+    den_t = E.sub(z, E.lift(fld.exp(g, n - 1)))                               # x - g^(n-1)
+    groups = {}
+    curl = fld.unpack(cur.reshape(-1))
+    for (col, step, val), cc in zip(c["assertions"], c["cc_b"]):
+        ev = E.sub(curl[col * D:(col + 1) * D], E.lift(val))
+        groups.setdefault(step, [0] * D)
+        groups[step] = E.add(groups[step], E.mul(cc, ev))
+    divs = {step: E.sub(z, E.lift(fld.exp(g, step))) for step in groups}
+    H = E.horner([fld.unpack(row) for row in co], z)
+    # H * num_t * prod(divs) == T * den_t * prod(divs) + sum_g B_g * num_t * prod(divs except g)
+    prod_all = E.lift(new(1))
+    for d in divs.values():
+        prod_all = E.mul(prod_all, d)
+    lhs = E.mul(E.mul(H, num_t), prod_all)
+    rhs = E.mul(E.mul(T, den_t), prod_all)
+    for step, B in groups.items():
+        other = E.lift(new(1))
+        for s2, d in divs.items():
+            if s2 != step:
+                other = E.mul(other, d)
+        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
+    assert lhs == rhs
+
+
+@pytest.mark.parametrize("fname,air,n", [("f64", 0, 32), ("f128", 1, 32)])
+def test_invalid_trace_breaks_divisibility(oracle, fname, air, n):
+    """A trace that violates a transition constraint is not divisible by the divisor: the interpolated composition
+    polynomial spills over the degree bound (what the prover's debug degree validation catches)."""
+    c = _case(oracle, fname, air, n, 1, 3, corrupt=True)
+    co = _composition_coeffs(c)
+    assert co[c["ncols"] * n:].any()
+
+
+def test_periodic_value_table_reference_example(oracle):
+    """prover/src/constraints/evaluator/periodic_table.rs:100-146: periodic values at ce step i equal the column's
+    polynomial at x_i^(n / cycle) — checked here for the Rescue AIR's 9 periodic columns through the evaluator: with all
+    coefficients on constraint k only, no assertions weight, the flag column must reproduce CYCLE_MASK on the trace domain."""
+    fld = oracle.f128
+    polys = fld.air_periodic_polys(fld.AIR_RESCUE)
+    g16 = fld.root_of_unity(4)
+    for i in range(16):
+        x = fld.exp(g16, i)
+        vals = fld.unpack(fld.evaluate_columns_at(polys, 9, fld.pack([x]), 1, 1).reshape(-1))
+        assert vals[0] == (1 if i < 14 else 0)                                   # CYCLE_MASK, examples/src/rescue/air.rs:18-35
+    # x -> x^(n/16) maps the trace domain onto the 16-cycle: hash_flag(g^i) = mask[i % 16]
+    n = 64
+    g = fld.root_of_unity(6)
+    for i in (0, 13, 14, 15, 16, 30, 47, 63):
+        x = fld.exp(fld.exp(g, i), n // 16)
+        assert fld.unpack(fld.evaluate_columns_at(polys[:1], 1, fld.pack([x]), 1, 1).reshape(-1))[0] == (1 if i % 16 < 14 else 0)
