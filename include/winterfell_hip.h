@@ -176,6 +176,32 @@ int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_deg
 int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row, uint32_t elem_bytes,
                   const uint64_t *h_positions, uint32_t count, void *h_out);
 
+/* ---- prover::constraints (constraint evaluation for the example AIRs) -------------------------------- */
+/* AIR transition functions are user code in the reference (Air::evaluate_transition closures), so only the AIRs the
+ * reference ships as examples are built in: */
+enum {
+    WF_AIR_FIB_SMALL = 0,   /* examples/src/fibonacci/fib_small/air.rs (2 columns, any field)                         */
+    WF_AIR_RESCUE = 1       /* examples/src/rescue/air.rs + rescue.rs (4 columns, 9 periodic columns, f128 only)      */
+};
+
+/* DefaultConstraintEvaluator::evaluate for a single-segment trace (prover/src/constraints/evaluator/default.rs:52-106,
+ * 165-210) followed by ConstraintEvaluationTable::combine (evaluation_table.rs:163-176,317-407): for every step of the
+ * constraint-evaluation domain (2^(log_n + log_ce_blowup) points) read the frame (rows step and step + 1 trace step)
+ * from the device-resident row-major trace LDE (RowMatrix layout, row_width words per row), evaluate the AIR's
+ * transition constraints, merge them with h_cc_transition, divide by the transition divisor
+ * (x^n - 1) / (x - g^(n-1)) (air/src/air/divisor.rs:43-51), add every boundary group
+ * sum_a cc_a (state[col_a] - value_a) / (x - g^step_a) (evaluator/boundary.rs:213-232,318-327; divisor.rs:55-71).
+ * Assertions are single-value (Assertion::single): columns / steps / values (base field, internal form) / coefficients
+ * (ext_degree words each) in any order — the result does not depend on it.  log_ce_blowup must be the AIR's
+ * ce_blowup_factor (FibSmall 2, Rescue 4; air/src/air/context.rs:104-117), log_lde_blowup >= log_ce_blowup.
+ * d_out: 2^(log_n + log_ce_blowup) elements of ext_degree words = CompositionPolyTrace, the input of
+ * CompositionPoly::new (wf_fft_interpolate_poly_with_offset). */
+int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                            uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                            const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                            const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
+                            void *d_out);
+
 /* ---- prover::composer (DEEP composition) and out-of-domain frames ------------------------------------- */
 /* ColMatrix::evaluate_columns_at for one or more points (prover/src/matrix/col_matrix.rs; polynom::eval,
  * math/src/polynom/mod.rs:55-61).  TracePolyTable::get_ood_frame (prover/src/trace/poly_table.rs:68-76) and

@@ -1,0 +1,152 @@
+"""GPU parity: constraint evaluation for the built-in example AIRs (wf_evaluate_constraints) against the CPU oracle's
+restatement of DefaultConstraintEvaluator + ConstraintEvaluationTable::combine, and the prover pipeline around it."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import air, crypto, prover
+    from winterfell_amd.math import fields
+    return winterfell_amd.default_context(), prover, fields, air, crypto
+
+
+def _rand_words(fld, count, seed):
+    rng = np.random.default_rng(seed)
+    if fld.W == 1:
+        return rng.integers(1, fld.M, size=count, dtype=np.uint64)
+    vals = [(int(a) << 64 | int(b)) % fld.M for a, b in zip(rng.integers(0, 2**63, size=count), rng.integers(1, 2**63, size=count, dtype=np.uint64))]
+    return fld.pack(vals)
+
+
+def _setup(oracle, fields, air_mod, fname, air_id, n, blowup):
+    fld, ofld = {"f64": (fields.f64, oracle.f64t), "f128": (fields.f128, oracle.f128), "f62": (fields.f62, oracle.f62)}[fname]
+    if air_id == 0:
+        trace = ofld.fib_small_build_trace(n)
+        air = air_mod.FibSmall(n, fld.unpack(trace[1])[n - 1], blowup, fld)
+    else:
+        trace = ofld.rescue_build_trace([42, 43], n // 16)
+        t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
+        air = air_mod.RescueAir(n, [t0[0], t1[0]], [t0[n - 1], t1[n - 1]], blowup)
+    return fld, ofld, trace, air
+
+
+def _gpu_eval(ctx, prover, crypto, fld, trace, air, D, blowup, seed):
+    domain = prover.StarkDomain(air.trace_length(), blowup, field=fld)
+    lde, polys = prover.DefaultTraceLde.new(crypto.Blake3_256, prover.ColMatrix(trace, 1, ctx, fld), domain)
+    ew = D * fld.W
+    cc = prover.ConstraintCompositionCoefficients(_rand_words(fld, air.num_transition_constraints() * D, seed).reshape(-1, ew),
+                                                  _rand_words(fld, air.num_assertions() * D, seed + 1).reshape(-1, ew))
+    ev = prover.DefaultConstraintEvaluator(air, cc, D)
+    return ev.evaluate(lde, domain), cc, ev, lde, polys, domain
+
+
+CASES = [("f64", 0, 8, 1, 8), ("f64", 0, 64, 2, 8), ("f64", 0, 4096, 3, 2), ("f62", 0, 256, 2, 4), ("f128", 0, 128, 1, 8),
+         ("f128", 1, 32, 1, 8), ("f128", 1, 1024, 2, 4), ("f128", 1, 16, 2, 16)]
+
+
+@pytest.mark.parametrize("fname,air_id,n,D,blowup", CASES)
+def test_evaluate_constraints_vs_oracle(wf, oracle, fname, air_id, n, D, blowup):
+    ctx, prover, fields, air_mod, crypto = wf
+    fld, ofld, trace, air = _setup(oracle, fields, air_mod, fname, air_id, n, blowup)
+    out, cc, ev, lde, polys, domain = _gpu_eval(ctx, prover, crypto, fld, trace, air, D, blowup, 7 * n + D)
+    o_lde = ofld.build_trace_commitment(0, trace, blowup, int(domain.offset))[1]
+    want = ofld.evaluate_constraints(air.AIR_ID, o_lde, o_lde.shape[1] // fld.W, n, blowup, air.ce_blowup_factor(), int(domain.offset), D,
+                                     cc.transition.reshape(-1), [(a.column, a.first_step, fld.pack([a.value])) for a in ev.assertions],
+                                     cc.boundary.reshape(-1))
+    assert np.array_equal(ctx.to_host(out), want)
+
+
+def test_argument_checks(wf, oracle):
+    ctx, prover, fields, air_mod, crypto = wf
+    from winterfell_amd._lib import WfError
+    fld, ofld, trace, air = _setup(oracle, fields, air_mod, "f64", 0, 16, 8)
+    out, cc, ev, lde, polys, domain = _gpu_eval(ctx, prover, crypto, fld, trace, air, 1, 8, 1)
+    air._ce_blowup = 4                                      # not the AIR's ce_blowup_factor
+    with pytest.raises(WfError):
+        ev.evaluate(lde, domain)
+    air._ce_blowup = 2
+    air.AIR_ID = 1                                          # Rescue constants only exist over f128
+    with pytest.raises(WfError):
+        ev.evaluate(lde, domain)
+    air.AIR_ID = 0
+    ev.assertions[0].column = 5                             # column out of range
+    with pytest.raises(WfError):
+        ev.evaluate(lde, domain)
+    with pytest.raises(AssertionError, match="blowup factor too small"):
+        air_mod.RescueAir(64, [1, 2], [3, 4], blowup_factor=2)
+    with pytest.raises(AssertionError, match="composition coefficient"):
+        prover.DefaultConstraintEvaluator(air_mod.FibSmall(16, 1), prover.ConstraintCompositionCoefficients(np.zeros(3, np.uint64), np.zeros(3, np.uint64)))
+
+
+@pytest.mark.parametrize("fname,air_id,log_n,D", [("f64", 0, 20, 2), ("f128", 1, 16, 2), ("f128", 1, 20, 1)])
+def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
+    """BASELINE configs[2] shape (examples::rescue, 2^20 rows, blowup 8) and fib_small at 2^20: trace commitment ->
+    constraint evaluation -> composition polynomial -> constraint commitment, everything device resident.  Checked:
+    exact divisibility (the composition polynomial fits num_constraint_composition_columns * n coefficients and its top
+    column is non-trivial), and the verifier's consistency equation at a random out-of-domain point z
+    (verifier/src/evaluator.rs:16-89): constraints evaluated on the OOD frame == sum_i z^(i n) H_i(z)."""
+    ctx, prover, fields, air_mod, crypto = wf
+    from test_oracle_deep import Ext
+    from winterfell_amd.math import fft
+    n, blowup = 1 << log_n, 8
+    fld, ofld, trace, air = _setup(oracle, fields, air_mod, fname, air_id, n, blowup)
+    out, cc, ev, lde, polys, domain = _gpu_eval(ctx, prover, crypto, fld, trace, air, D, blowup, 99)
+    ncols, ce = air.num_constraint_composition_columns(), air.ce_domain_size()
+    coeffs = fft.interpolate_poly_with_offset(out.clone(), None, domain.offset, ext_degree=D, ctx=ctx, field=fld)
+    co = ctx.to_host(coeffs).reshape(ce, D * fld.W)
+    assert not co[ncols * n:].any() and co[(ncols - 1) * n:ncols * n].any()
+    commitment, cpoly = prover.build_constraint_commitment(crypto.Blake3_256, out, ncols, domain, ext_degree=D, field=fld, ctx=ctx)
+    assert cpoly.num_columns() == ncols and commitment.evaluations.num_rows() == n * blowup
+    # ---- verifier-side check at z
+    E = Ext(ofld, D)
+    rng = np.random.default_rng(11)
+    z = [int(rng.integers(1, 2**62)) % fld.M for _ in range(D)]
+    zw = fld.pack(z)
+    table = prover.TracePolyTable(polys)
+    cur, nxt = table.get_ood_frame(zw, D)
+    qcur, _ = prover.composition_poly_ood_frame(cpoly, zw, D)
+    one = fld.new(1)
+    g = fld.new(fld.get_root_of_unity(log_n))
+
+    def zpow(e):
+        r, b = E.lift(one), z
+        while e:
+            if e & 1:
+                r = E.mul(r, b)
+            b = E.mul(b, b)
+            e >>= 1
+        return r
+    zn = zpow(n)
+    H, zi = [0] * D, E.lift(one)
+    for i in range(ncols):                                  # sum_i z^(i n) H_i(z), verifier/src/lib.rs ood check
+        H = E.add(H, E.mul(zi, fld.unpack(qcur[i])))
+        zi = E.mul(zi, zn)
+    per = np.zeros(0, dtype=np.uint64)
+    if air_id == 1:
+        per = ofld.evaluate_columns_at(ofld.air_periodic_polys(1), 9, fld.pack(zpow(n // 16)), D, 1).reshape(-1)
+    tev = fld.unpack(ofld.air_evaluate_transition(air_id, D, cur.reshape(-1), nxt.reshape(-1), per))
+    T = [0] * D
+    for k in range(air.num_transition_constraints()):
+        T = E.add(T, E.mul(fld.unpack(cc.transition[k]), tev[k * D:(k + 1) * D]))
+    num_t, den_t = E.sub(zn, E.lift(one)), E.sub(z, E.lift(ofld.exp(g, n - 1)))
+    groups, curl = {}, fld.unpack(cur.reshape(-1))
+    for a, ccb in zip(ev.assertions, cc.boundary):
+        evl = E.sub(curl[a.column * D:(a.column + 1) * D], E.lift(a.value))
+        groups[a.first_step] = E.add(groups.get(a.first_step, [0] * D), E.mul(fld.unpack(ccb), evl))
+    divs = {s: E.sub(z, E.lift(ofld.exp(g, s))) for s in groups}
+    prod_all = E.lift(one)
+    for d in divs.values():
+        prod_all = E.mul(prod_all, d)
+    lhs = E.mul(E.mul(H, num_t), prod_all)
+    rhs = E.mul(E.mul(T, den_t), prod_all)
+    for s, B in groups.items():
+        other = E.lift(one)
+        for s2, d in divs.items():
+            if s2 != s:
+                other = E.mul(other, d)
+        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
+    assert lhs == rhs

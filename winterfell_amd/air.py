@@ -1,0 +1,120 @@
+"""The slice of the reference's `air` crate the GPU constraint evaluator needs: Assertion::single, the AirContext
+arithmetic (ce_blowup_factor, number of composition columns, transition exemptions) and the two example AIRs whose
+transition functions are built into the library (include/winterfell_hip.h: WF_AIR_FIB_SMALL, WF_AIR_RESCUE).
+
+Values are python ints in the field's INTERNAL representation (fields.Field.new / as_int)."""
+from .math import fields
+
+MIN_BLOWUP_FACTOR = 2          # air/src/options.rs ProofOptions::MIN_BLOWUP_FACTOR
+
+
+class Assertion:
+    """Assertion::single(column, step, value) (air/src/air/assertions/mod.rs:76-85); stride 0, one value."""
+
+    def __init__(self, column, step, value):
+        self.column, self.first_step, self.stride, self.value = column, step, 0, value
+
+    @classmethod
+    def single(cls, column, step, value):
+        return cls(column, step, value)
+
+    def sort_key(self):
+        """Ord for Assertion: stride, then first_step, then column (assertions/mod.rs:301-315)."""
+        return (self.stride, self.first_step, self.column)
+
+
+class TransitionConstraintDegree:
+    """air/src/air/transition/degree.rs:30-116."""
+
+    def __init__(self, base, cycles=()):
+        assert base > 0, "transition constraint degree must be at least one, but was zero"
+        for c in cycles:
+            assert c >= 2 and c & (c - 1) == 0
+        self.base, self.cycles = base, list(cycles)
+
+    def get_evaluation_degree(self, trace_length):
+        return self.base * (trace_length - 1) + sum((trace_length // c) * (c - 1) for c in self.cycles)
+
+    def min_blowup_factor(self):
+        bound = self.base + len(self.cycles) - 1
+        npo2 = 1 if bound <= 1 else 1 << (bound - 1).bit_length()
+        return max(npo2, MIN_BLOWUP_FACTOR)
+
+
+class _BuiltinAir:
+    AIR_ID = None
+    TRACE_WIDTH = None
+    FIELD = None
+
+    def __init__(self, trace_length, degrees, num_assertions, blowup_factor):
+        assert trace_length >= 8 and trace_length & (trace_length - 1) == 0       # TraceInfo::MIN_TRACE_LENGTH
+        self._n, self.degrees, self._num_assertions, self.blowup_factor = trace_length, degrees, num_assertions, blowup_factor
+        self._ce_blowup = max(d.min_blowup_factor() for d in degrees)               # context.rs:104-117
+        assert blowup_factor >= self._ce_blowup, \
+            "blowup factor too small; expected at least %d, but was %d" % (self._ce_blowup, blowup_factor)   # context.rs:119-124
+
+    def trace_length(self):
+        return self._n
+
+    def ce_blowup_factor(self):
+        return self._ce_blowup
+
+    def ce_domain_size(self):
+        return self._n * self._ce_blowup
+
+    def lde_domain_size(self):
+        return self._n * self.blowup_factor
+
+    def num_transition_constraints(self):
+        return len(self.degrees)
+
+    def num_assertions(self):
+        return self._num_assertions
+
+    def num_transition_exemptions(self):
+        return 1                                                                   # context.rs:134
+
+    def num_constraint_composition_columns(self):
+        """context.rs:265-285."""
+        highest = max(d.get_evaluation_degree(self._n) for d in self.degrees)
+        divisor_degree = self._n - self.num_transition_exemptions()
+        return max(-(-(highest - divisor_degree) // self._n), 1)
+
+    def sorted_assertions(self):
+        """prepare_assertions (air/src/air/boundary/mod.rs:181-208): the order composition coefficients are dealt in."""
+        a = sorted(self.get_assertions(), key=Assertion.sort_key)
+        assert len(a) == self._num_assertions
+        for x in a:
+            assert x.column < self.TRACE_WIDTH and x.first_step < self._n
+        return a
+
+
+class FibSmall(_BuiltinAir):
+    """examples/src/fibonacci/fib_small/air.rs:15-68 (the reference instantiates it over f64; the AIR itself is field
+    agnostic and so is the kernel)."""
+    AIR_ID, TRACE_WIDTH = 0, 2
+
+    def __init__(self, trace_length, result, blowup_factor=8, field=fields.f64):
+        super().__init__(trace_length, [TransitionConstraintDegree(1), TransitionConstraintDegree(1)], 3, blowup_factor)
+        self.result, self.FIELD = result, field
+
+    def get_assertions(self):
+        one = self.FIELD.new(1)
+        last = self._n - 1
+        return [Assertion.single(0, 0, one), Assertion.single(1, 0, one), Assertion.single(1, last, self.result)]
+
+
+class RescueAir(_BuiltinAir):
+    """examples/src/rescue/air.rs:54-129 (f128; 14 Rescue rounds per 16-step cycle, 9 periodic columns)."""
+    AIR_ID, TRACE_WIDTH, CYCLE_LENGTH = 1, 4, 16
+    FIELD = fields.f128
+
+    def __init__(self, trace_length, seed, result, blowup_factor=8):
+        deg = [TransitionConstraintDegree(3, [self.CYCLE_LENGTH]) for _ in range(4)]
+        super().__init__(trace_length, deg, 4, blowup_factor)
+        self.seed, self.result = list(seed), list(result)
+
+    def get_assertions(self):
+        last = self._n - 1
+        return [Assertion.single(0, 0, self.seed[0]), Assertion.single(1, 0, self.seed[1]),
+                Assertion.single(0, last, self.result[0]), Assertion.single(1, last, self.result[1])]

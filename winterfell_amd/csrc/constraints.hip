@@ -1,0 +1,455 @@
+// Constraint evaluation over the constraint-evaluation domain for the reference's example AIRs.
+//
+// Reference behaviour reproduced (single-segment traces, single-value assertions):
+//   DefaultConstraintEvaluator::evaluate / evaluate_fragment_main / evaluate_main_transition
+//                                         prover/src/constraints/evaluator/default.rs:52-106,165-210,277-299
+//   BoundaryConstraints::evaluate_main    prover/src/constraints/evaluator/boundary.rs:86-97,213-232,318-327
+//   PeriodicValueTable                    prover/src/constraints/evaluator/periodic_table.rs:24-88
+//   ConstraintEvaluationTable::combine    prover/src/constraints/evaluation_table.rs:163-176,317-407
+//   ConstraintDivisor                     air/src/air/divisor.rs:43-71,120-123
+//   read_main_trace_frame_into            prover/src/trace/trace_lde/default/mod.rs:171-185
+//   AIRs: FibSmall (examples/src/fibonacci/fib_small/air.rs:41-59), RescueAir (examples/src/rescue/air.rs:88-138,
+//         examples/src/rescue/rescue.rs:60-123; f128 only, constants generated into rescue_f128_constants.h)
+//
+// AIR transition functions are user Rust closures in the reference, so they cannot cross a C ABI generically: the two
+// example AIRs are hand-written device functions selected by `air`.  Everything around them is generic: one lane per
+// constraint-evaluation step reads its frame straight from the device-resident row-major LDE (no D2H copy of the
+// trace), folds the transition evaluations with the composition coefficients, multiplies by the inverse divisor
+// 1 / (x^n - 1) * (x - g^(n-1)), adds the boundary groups divided by (x - g^step), and writes the combined value.
+// The per-step inverses 1 / (x_i - g^step) come from a batch-inversion kernel (16 steps per lane, one field inversion).
+#include <string.h>
+
+#include <vector>
+
+#include "dft_regs.cuh"
+#include "tables.cuh"
+#include "wf_internal.h"
+
+#define RESCUE_CONST static const
+#include "rescue_f128_constants.h"
+
+namespace {
+
+constexpr int MAX_GROUPS = 8;
+constexpr int MAX_ASSERT = 64;
+constexpr int INV_CHUNK = 16;
+
+// ---- AIRs -------------------------------------------------------------------------------------------------------
+struct AirFibSmall {
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1;
+    struct Consts {};
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
+                                                      const Consts &, typename F::T *res) {
+        res[0] = F::sub(next[0], F::add(cur[0], cur[1]));     // s_{0,i+1} = s_{0,i} + s_{1,i}
+        res[1] = F::sub(next[1], F::add(cur[1], next[0]));    // s_{1,i+1} = s_{1,i} + s_{0,i+1}
+    }
+};
+
+struct AirRescue {   // F128 only
+    static constexpr int WIDTH = 4, NT = 4, NP = 9, CYCLE = 16, LOG_CE = 2;
+    struct Consts {
+        f128::u128 mds[16], inv_mds[16];
+    };
+    template <class F>
+    static __device__ __forceinline__ void mds(typename F::T (&st)[4], const f128::u128 *m) {
+        typename F::T r[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            r[i] = F::mul(m[i * 4], st[0]);
+#pragma unroll
+            for (int j = 1; j < 4; j++) r[i] = F::add(r[i], F::mul(m[i * 4 + j], st[j]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) st[i] = r[i];
+    }
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *per,
+                                                      const Consts &c, typename F::T *res) {
+        typedef typename F::T T;
+        const T flag = per[0];
+        const T *ark = per + 1;
+        T s1[4], s2[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) s1[i] = F::mul(F::mul(cur[i], cur[i]), cur[i]);           // apply_sbox
+        mds<F>(s1, c.mds);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s1[i] = F::add(s1[i], ark[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s2[i] = F::sub(next[i], ark[4 + i]);
+        mds<F>(s2, c.inv_mds);
+#pragma unroll
+        for (int i = 0; i < 4; i++) s2[i] = F::mul(F::mul(s2[i], s2[i]), s2[i]);
+        const T copy_flag = F::sub((T)1, flag);                                               // not(hash_flag); f128: ONE = 1
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const T round = F::mul(flag, F::sub(s2[i], s1[i]));
+            const T copy = F::mul(copy_flag, i < 2 ? F::sub(cur[i], next[i]) : next[i]);
+            res[i] = F::add(round, copy);
+        }
+    }
+};
+
+// ---- field inversion by exponentiation (exponent = modulus - 2, passed in as two words) ---------------------------
+template <class F>
+__device__ __forceinline__ typename F::T field_inv(typename F::T a, typename F::T one, uint64_t e_lo, uint64_t e_hi) {
+    typename F::T r = one;
+    bool started = false;
+    for (int bit = 127; bit >= 0; bit--) {
+        const uint64_t w = bit >= 64 ? e_hi : e_lo;
+        const bool set = (w >> (bit & 63)) & 1;
+        if (started) r = F::mul(r, r);
+        if (set) {
+            r = started ? F::mul(r, a) : a;
+            started = true;
+        }
+    }
+    return r;
+}
+
+// zb[q][i] = 1 / (x_i - b_q),  x_i = offset * g_ce^i  (series table),  INV_CHUNK consecutive i per lane
+template <class F>
+__global__ __launch_bounds__(256) void divisor_inv_kernel(const typename F::T *x_lo, const typename F::T *x_hi, uint32_t x_log_lo,
+                                                          uint64_t ce, const typename F::T *b, typename F::T one, uint64_t e_lo,
+                                                          uint64_t e_hi, typename F::T *zb) {
+    typedef typename F::T T;
+    const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * INV_CHUNK;
+    if (i0 >= ce) return;
+    const uint32_t q = blockIdx.y;
+    const T bq = b[q];
+    const uint32_t cnt = ce - i0 < INV_CHUNK ? (uint32_t)(ce - i0) : INV_CHUNK;
+    T v[INV_CHUNK], pre[INV_CHUNK];
+    T acc = one;
+#pragma unroll
+    for (int k = 0; k < INV_CHUNK; k++) {
+        if ((uint32_t)k < cnt) {
+            v[k] = F::sub(series_at<F>(x_lo, x_hi, x_log_lo, i0 + k), bq);
+            pre[k] = acc;
+            acc = F::mul(acc, v[k]);
+        }
+    }
+    acc = field_inv<F>(acc, one, e_lo, e_hi);
+#pragma unroll
+    for (int k = INV_CHUNK - 1; k >= 0; k--) {
+        if ((uint32_t)k < cnt) {
+            zb[(uint64_t)q * ce + i0 + k] = F::mul(acc, pre[k]);
+            acc = F::mul(acc, v[k]);
+        }
+    }
+}
+
+template <class T, int D>
+struct EvalParams {
+    const T *lde;
+    uint64_t row_width;
+    uint32_t log_n, log_lde_blowup, log_ce_blowup;
+    const T *x_lo, *x_hi;         // x_i = offset * g_ce^i
+    uint32_t x_log_lo;
+    const T *ptab;                // periodic table [plen][NP]
+    const T *zt;                  // [ce_blowup] inverse transition-divisor numerators
+    T exempt;                     // g^(n-1)
+    const T *zb;                  // [ngroups][ce]
+    const T *cc_t;                // [NT][D]
+    uint32_t num_assert, ngroups;
+    const uint32_t *a_col, *a_group;
+    const T *a_val;               // [num_assert]
+    const T *cc_b;                // [num_assert][D]
+    T *out;                       // [ce][D]
+};
+
+template <class F, class AIR, int D>
+__global__ __launch_bounds__(256) void constraints_kernel(EvalParams<typename F::T, D> p, typename AIR::Consts consts) {
+    typedef typename F::T T;
+    const uint64_t ce = 1ull << (p.log_n + p.log_ce_blowup);
+    const uint64_t step = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (step >= ce) return;
+    const uint64_t lde_rows = 1ull << (p.log_n + p.log_lde_blowup);
+    const uint64_t lde_step = step << (p.log_lde_blowup - p.log_ce_blowup);
+    const T *rc = p.lde + lde_step * p.row_width;
+    const T *rn = p.lde + ((lde_step + (1ull << p.log_lde_blowup)) & (lde_rows - 1)) * p.row_width;
+    T cur[AIR::WIDTH], next[AIR::WIDTH], per[AIR::NP > 0 ? AIR::NP : 1], tev[AIR::NT];
+#pragma unroll
+    for (int k = 0; k < AIR::WIDTH; k++) {
+        cur[k] = F::load_norm(rc[k]);
+        next[k] = F::load_norm(rn[k]);
+    }
+    if (AIR::NP > 0) {
+        const uint32_t plen = (uint32_t)AIR::CYCLE << p.log_ce_blowup;
+        const T *row = p.ptab + (size_t)(step & (plen - 1)) * AIR::NP;
+#pragma unroll
+        for (int k = 0; k < AIR::NP; k++) per[k] = row[k];
+    }
+    AIR::template transition<F>(cur, next, per, consts, tev);
+    T acc[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+        acc[d] = F::mul(p.cc_t[d], tev[0]);
+#pragma unroll
+        for (int k = 1; k < AIR::NT; k++) acc[d] = F::add(acc[d], F::mul(p.cc_t[k * D + d], tev[k]));
+    }
+    const T x = series_at<F>(p.x_lo, p.x_hi, p.x_log_lo, step);
+    const T ze = F::mul(p.zt[step & ((1u << p.log_ce_blowup) - 1)], F::sub(x, p.exempt));
+#pragma unroll
+    for (int d = 0; d < D; d++) acc[d] = F::mul(acc[d], ze);
+    for (uint32_t q = 0; q < p.ngroups; q++) {
+        T grp[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) grp[d] = F::zero();
+        for (uint32_t k = 0; k < p.num_assert; k++) {
+            if (p.a_group[k] != q) continue;
+            // state[column] with a uniform column index: select without dynamic register indexing
+            T sv = cur[0];
+            const uint32_t col = p.a_col[k];
+#pragma unroll
+            for (int c = 1; c < AIR::WIDTH; c++) sv = col == (uint32_t)c ? cur[c] : sv;
+            const T ev = F::sub(sv, p.a_val[k]);
+#pragma unroll
+            for (int d = 0; d < D; d++) grp[d] = F::add(grp[d], F::mul(p.cc_b[k * D + d], ev));
+        }
+        const T z = p.zb[(uint64_t)q * ce + step];
+#pragma unroll
+        for (int d = 0; d < D; d++) acc[d] = F::add(acc[d], F::mul(grp[d], z));
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) p.out[step * D + d] = acc[d];
+}
+
+// ---- host side --------------------------------------------------------------------------------------------------------
+template <class HF>
+struct HostOps {
+    typedef typename HF::T T;
+    static T modulus();
+};
+template <> HostF64::T HostOps<HostF64>::modulus() { return gl::P; }
+template <> HostF128::T HostOps<HostF128>::modulus() { return f128::modulus(); }
+template <> HostF62::T HostOps<HostF62>::modulus() { return f62::M; }
+
+template <class HF>
+static typename HF::T hadd(typename HF::T a, typename HF::T b) {
+    const typename HF::T m = HostOps<HF>::modulus();
+    const typename HF::T s = a + b;            // may wrap for f128: detect
+    if (s < a || s >= m) return s - m;
+    return s;
+}
+template <class HF>
+static typename HF::T hsub(typename HF::T a, typename HF::T b) {
+    return a >= b ? a - b : a + (HostOps<HF>::modulus() - b);
+}
+
+// periodic column values of the AIR (canonical integers), NP columns of CYCLE values
+template <class HF, class AIR>
+static void periodic_values(std::vector<std::vector<typename HF::T>> &cols);
+template <> void periodic_values<HostF64, AirFibSmall>(std::vector<std::vector<HostF64::T>> &cols) { cols.clear(); }
+template <> void periodic_values<HostF128, AirFibSmall>(std::vector<std::vector<HostF128::T>> &cols) { cols.clear(); }
+template <> void periodic_values<HostF62, AirFibSmall>(std::vector<std::vector<HostF62::T>> &cols) { cols.clear(); }
+template <> void periodic_values<HostF128, AirRescue>(std::vector<std::vector<HostF128::T>> &cols) {
+    cols.assign(9, std::vector<HostF128::T>(16));
+    for (int i = 0; i < 16; i++) cols[0][i] = i < 14 ? 1 : 0;                 // CYCLE_MASK, examples/src/rescue/air.rs:18-35
+    for (int j = 0; j < 8; j++)
+        for (int i = 0; i < 16; i++) cols[1 + j][i] = RESCUE_ARK[i][j];      // get_round_constants, rescue.rs:92-107
+}
+
+template <class AIR>
+static void fill_consts(typename AIR::Consts &c);
+template <> void fill_consts<AirFibSmall>(AirFibSmall::Consts &) {}
+template <> void fill_consts<AirRescue>(AirRescue::Consts &c) {
+    for (int i = 0; i < 16; i++) {
+        c.mds[i] = RESCUE_MDS[i];
+        c.inv_mds[i] = RESCUE_INV_MDS[i];
+    }
+}
+
+template <class HF, class AIR, int D>
+static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup,
+                    const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols, const uint64_t *h_steps,
+                    const void *h_vals, const void *h_cc_b, void *d_out) {
+    typedef typename HF::T T;
+    typedef typename HF::Dev F;
+    if (log_ce_blowup != (uint32_t)AIR::LOG_CE) return WF_ERR_INVALID_ARG;          // AirContext fixes ce_blowup (context.rs:104-117)
+    if (log_lde_blowup < log_ce_blowup) return WF_ERR_INVALID_ARG;                  // "blowup factor too small" (context.rs:119-124)
+    if (row_width < (uint64_t)AIR::WIDTH || num_assert == 0 || num_assert > MAX_ASSERT) return WF_ERR_INVALID_ARG;
+    if (log_n + log_lde_blowup > HF::TWO_ADICITY || log_n < 3) return WF_ERR_DOMAIN_TOO_LARGE;
+    if (AIR::CYCLE && (1ull << log_n) < (uint64_t)AIR::CYCLE) return WF_ERR_INVALID_ARG;
+    const uint64_t n = 1ull << log_n, ce = n << log_ce_blowup;
+    const uint32_t ce_blowup = 1u << log_ce_blowup, log_ce = log_n + log_ce_blowup;
+    T off;
+    WF_TRY(wf_load_offset<HF>(h_offset, &off));
+    const T g_ce = HF::root_of_unity(log_ce), g_trace = HF::root_of_unity(log_n);
+    const T one_c = HF::from_u64(1);
+
+    // boundary groups by asserted step
+    uint64_t gsteps[MAX_GROUPS];
+    uint32_t ngroups = 0;
+    std::vector<uint32_t> a_group(num_assert), a_col(num_assert);
+    std::vector<T> a_val(num_assert), cc_b((size_t)num_assert * D), cc_t((size_t)AIR::NT * D);
+    for (uint32_t k = 0; k < num_assert; k++) {
+        if (h_cols[k] >= (uint32_t)AIR::WIDTH || h_steps[k] >= n) return WF_ERR_INVALID_ARG;
+        uint32_t q = 0;
+        while (q < ngroups && gsteps[q] != h_steps[k]) q++;
+        if (q == ngroups) {
+            if (ngroups == MAX_GROUPS) return WF_ERR_UNSUPPORTED;
+            gsteps[ngroups++] = h_steps[k];
+        }
+        a_group[k] = q;
+        a_col[k] = h_cols[k];
+        memcpy((void *)&a_val[k], (const uint8_t *)h_vals + (size_t)k * sizeof(T), sizeof(T));
+        if (!HF::valid_internal(a_val[k])) return WF_ERR_INVALID_ARG;
+        a_val[k] = HF::to_internal(HF::from_internal(a_val[k]));               // normalise lazy f62 words
+    }
+    memcpy((void *)cc_b.data(), h_cc_b, cc_b.size() * sizeof(T));
+    memcpy((void *)cc_t.data(), h_cc_t, cc_t.size() * sizeof(T));
+    for (auto &v : cc_b) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+    for (auto &v : cc_t) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+
+    // transition divisor: inverse of x^n - 1 over its ce_blowup distinct values (get_inv_evaluation), exemption g^(n-1)
+    std::vector<T> zt(ce_blowup);
+    {
+        const T off_n = HF::powmod(off, n);
+        const T g_b = HF::powmod(g_ce, n);                                      // g_ce^n: a ce_blowup-th root of unity
+        T cur = off_n;
+        for (uint32_t i = 0; i < ce_blowup; i++) {
+            zt[i] = HF::to_internal(HF::invmod(hsub<HF>(cur, one_c)));
+            cur = HF::mulmod(cur, g_b);
+        }
+    }
+    const T exempt = HF::to_internal(HF::powmod(g_trace, n - 1));
+    std::vector<T> bvals(ngroups);
+    for (uint32_t q = 0; q < ngroups; q++) bvals[q] = HF::to_internal(HF::powmod(g_trace, gsteps[q]));
+
+    // periodic table (periodic_table.rs:24-75): column polynomial (inverse DFT of the cycle values) evaluated at
+    // offset^(n/cycle) * g_plen^i, i < plen = cycle * ce_blowup; laid out [i][column]
+    std::vector<std::vector<T>> pcols;
+    periodic_values<HF, AIR>(pcols);
+    const uint32_t plen = (uint32_t)AIR::CYCLE * ce_blowup;
+    std::vector<T> ptab((size_t)plen * AIR::NP + 1);
+    if (AIR::NP > 0) {
+        const uint32_t cyc = AIR::CYCLE;
+        uint32_t log_cyc = 0;
+        while ((1u << log_cyc) < cyc) log_cyc++;
+        const T w_inv = HF::invmod(HF::root_of_unity(log_cyc)), cyc_inv = HF::invmod(HF::from_u64(cyc));
+        uint32_t log_plen = 0;
+        while ((1u << log_plen) < plen) log_plen++;
+        const T g_p = HF::root_of_unity(log_plen), off_c = HF::powmod(off, n / cyc);
+        for (int k = 0; k < AIR::NP; k++) {
+            std::vector<T> poly(cyc);
+            for (uint32_t j = 0; j < cyc; j++) {                                // coefficient j = (1/cyc) sum_i v_i w^(-ij)
+                T s = 0;
+                const T wj = HF::powmod(w_inv, j);
+                T wij = one_c;
+                for (uint32_t i = 0; i < cyc; i++) {
+                    s = hadd<HF>(s, HF::mulmod(pcols[k][i], wij));
+                    wij = HF::mulmod(wij, wj);
+                }
+                poly[j] = HF::mulmod(s, cyc_inv);
+            }
+            T x = off_c;
+            for (uint32_t i = 0; i < plen; i++) {
+                T acc = 0;
+                for (uint32_t j = cyc; j-- > 0;) acc = hadd<HF>(HF::mulmod(acc, x), poly[j]);
+                ptab[(size_t)i * AIR::NP + k] = HF::to_internal(acc);
+                x = HF::mulmod(x, g_p);
+            }
+        }
+    }
+
+    // device staging: one scratch block
+    const size_t w_zb = (size_t)ngroups * ce, w_small = ptab.size() + zt.size() + bvals.size() + a_val.size() + cc_b.size() + cc_t.size();
+    const size_t bytes = (w_zb + w_small) * sizeof(T) + 2 * (size_t)num_assert * sizeof(uint32_t) + 64;
+    void *tmp;
+    WF_TRY(wf_scratch(ctx, 0, bytes, &tmp));
+    T *d_zb = (T *)tmp, *d_ptab = d_zb + w_zb, *d_zt = d_ptab + ptab.size(), *d_b = d_zt + zt.size(), *d_aval = d_b + bvals.size(),
+      *d_ccb = d_aval + a_val.size(), *d_cct = d_ccb + cc_b.size();
+    uint32_t *d_acol = (uint32_t *)(d_cct + cc_t.size()), *d_agrp = d_acol + num_assert;
+    auto up = [&](void *dst, const void *src, size_t nbytes) { return hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream); };
+    WF_HIP(up(d_ptab, ptab.data(), ptab.size() * sizeof(T)));
+    WF_HIP(up(d_zt, zt.data(), zt.size() * sizeof(T)));
+    WF_HIP(up(d_b, bvals.data(), bvals.size() * sizeof(T)));
+    WF_HIP(up(d_aval, a_val.data(), a_val.size() * sizeof(T)));
+    WF_HIP(up(d_ccb, cc_b.data(), cc_b.size() * sizeof(T)));
+    WF_HIP(up(d_cct, cc_t.data(), cc_t.size() * sizeof(T)));
+    WF_HIP(up(d_acol, a_col.data(), num_assert * sizeof(uint32_t)));
+    WF_HIP(up(d_agrp, a_group.data(), num_assert * sizeof(uint32_t)));
+    WF_HIP(hipStreamSynchronize(ctx->stream));      // host vectors die with this frame
+
+    SeriesTable xs;
+    WF_TRY(wf_get_series_table<HF>(ctx, g_ce, off, log_ce, &xs));
+    const T m2 = HostOps<HF>::modulus() - 2;
+    const uint64_t e_lo = (uint64_t)m2, e_hi = sizeof(T) > 8 ? (uint64_t)((unsigned __int128)m2 >> 64) : 0;
+    const T one_i = HF::to_internal(one_c);
+    {
+        const uint64_t lanes = (ce + INV_CHUNK - 1) / INV_CHUNK;
+        wf_prof_begin(ctx, "divisor_inv");
+        hipLaunchKernelGGL((divisor_inv_kernel<F>), dim3((uint32_t)((lanes + 255) / 256), ngroups), dim3(256), 0, ctx->stream,
+                           (const T *)xs.d_lo, (const T *)xs.d_hi, xs.log_lo, ce, (const T *)d_b, one_i, e_lo, e_hi, d_zb);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+    }
+    EvalParams<T, D> p;
+    p.lde = (const T *)d_lde;
+    p.row_width = row_width;
+    p.log_n = log_n;
+    p.log_lde_blowup = log_lde_blowup;
+    p.log_ce_blowup = log_ce_blowup;
+    p.x_lo = (const T *)xs.d_lo;
+    p.x_hi = (const T *)xs.d_hi;
+    p.x_log_lo = xs.log_lo;
+    p.ptab = d_ptab;
+    p.zt = d_zt;
+    p.exempt = exempt;
+    p.zb = d_zb;
+    p.cc_t = d_cct;
+    p.num_assert = num_assert;
+    p.ngroups = ngroups;
+    p.a_col = d_acol;
+    p.a_group = d_agrp;
+    p.a_val = d_aval;
+    p.cc_b = d_ccb;
+    p.out = (T *)d_out;
+    typename AIR::Consts consts;
+    fill_consts<AIR>(consts);
+    wf_prof_begin(ctx, "evaluate_constraints");
+    hipLaunchKernelGGL((constraints_kernel<F, AIR, D>), dim3((uint32_t)((ce + 255) / 256)), dim3(256), 0, ctx->stream, p, consts);
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+template <class HF, class AIR>
+static int evaluate_d(wf_ctx *ctx, uint32_t D, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup,
+                      uint32_t log_ce_blowup, const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols,
+                      const uint64_t *h_steps, const void *h_vals, const void *h_cc_b, void *d_out) {
+    if (D == 1) return evaluate<HF, AIR, 1>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
+    if (D == 2) return evaluate<HF, AIR, 2>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
+    if constexpr (HF::Dev::MAX_EXT >= 3)
+        if (D == 3) return evaluate<HF, AIR, 3>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
+    return WF_ERR_UNSUPPORTED;
+}
+
+}  // namespace
+
+extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                       uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                       const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                       const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
+                                       void *d_out) {
+    if (!ctx || !d_trace_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps || !h_assert_values ||
+        !h_cc_boundary || !d_out)
+        return WF_ERR_INVALID_ARG;
+#define WF_EVAL(HF, AIR)                                                                                                          \
+    return evaluate_d<HF, AIR>(ctx, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,    \
+                               h_cc_transition, num_assertions, h_assert_columns, h_assert_steps, h_assert_values, h_cc_boundary, d_out)
+    if (air == WF_AIR_FIB_SMALL) {
+        switch (field) {
+            case WF_FIELD_F64: WF_EVAL(HostF64, AirFibSmall);
+            case WF_FIELD_F128: WF_EVAL(HostF128, AirFibSmall);
+            case WF_FIELD_F62: WF_EVAL(HostF62, AirFibSmall);
+            default: return WF_ERR_UNSUPPORTED;
+        }
+    }
+    if (air == WF_AIR_RESCUE) {
+        if (field != WF_FIELD_F128) return WF_ERR_UNSUPPORTED;   // the example's constants live in f128 (examples/src/rescue/rescue.rs:8)
+        WF_EVAL(HostF128, AirRescue);
+    }
+#undef WF_EVAL
+    return WF_ERR_UNSUPPORTED;
+}

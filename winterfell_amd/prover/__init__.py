@@ -4,3 +4,4 @@ from .matrix import ColMatrix, RowMatrix, PartitionOptions  # noqa: F401
 from .trace_lde import DefaultTraceLde, StarkDomain, build_trace_commitment  # noqa: F401
 from .constraint_commitment import CompositionPoly, DefaultConstraintCommitment, build_constraint_commitment  # noqa: F401
 from .composer import DeepCompositionPoly, TracePolyTable, composition_poly_ood_frame, evaluate_columns_at  # noqa: F401
+from .constraints import ConstraintCompositionCoefficients, DefaultConstraintEvaluator  # noqa: F401
