@@ -152,7 +152,7 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/r01/bench_pmc_summary.json)",
-            "limiter": "VALU issue (SQ_ACTIVE_INST_VALU ~ 90% of kernel time, see DESIGN.md section 5)",
+            "limiter": "VALU issue (SQ_ACTIVE_INST_VALU x 4 cycles = 0.77 of the SIMD-cycles of a launch at the nominal 2.4 GHz; HBM traffic = 1.0x the data per pass; see DESIGN.md section 5)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
@@ -185,6 +185,29 @@ def main():
             cm128 = prover.ColMatrix(ctx.to_device(tr128), field=f128)
             dom128 = prover.StarkDomain(tn, tb, field=f128)
             ex["lde_commit_ms_2^20x4_b8_f128_blake3"] = timed(lambda: prover.build_trace_commitment(crypto.Blake3_256, cm128, dom128), 3)
+            # configs[2] end to end on the device: trace LDE + commit -> constraint evaluation (Rescue AIR) -> composition
+            # polynomial + constraint commitment -> OOD frames + DEEP composition + its LDE  (random trace: timing only)
+            from winterfell_amd import air as wair
+            rair = wair.RescueAir(tn, [1, 2], [3, 4], tb)
+            ew = 2 * f128.W
+            cc = prover.ConstraintCompositionCoefficients(rng.integers(1, 1 << 62, (4, ew), dtype=np.uint64),
+                                                          rng.integers(1, 1 << 62, (4, ew), dtype=np.uint64))
+            zpt = rng.integers(1, 1 << 62, ew, dtype=np.uint64)
+            cct, ccq = rng.integers(1, 1 << 62, (4, ew), dtype=np.uint64), rng.integers(1, 1 << 62, (3, ew), dtype=np.uint64)
+
+            def rescue_pipeline():
+                lde, polys = prover.DefaultTraceLde.new(crypto.Blake3_256, cm128, dom128)
+                ev_ = prover.DefaultConstraintEvaluator(rair, cc, 2).evaluate(lde, dom128)
+                com, cpoly = prover.build_constraint_commitment(crypto.Blake3_256, ev_, 3, dom128, ext_degree=2, field=f128, ctx=ctx)
+                table = prover.TracePolyTable(polys)
+                table.get_ood_frame(zpt, 2)
+                prover.composition_poly_ood_frame(cpoly, zpt, 2)
+                deep = prover.DeepCompositionPoly(zpt, cct, ccq, 2)
+                deep.add_trace_polys(table, cpoly)
+                return deep.evaluate(dom128)
+
+            ex["rescue_2^20_f128_quad_b8_commit+constraints+composition+deep_ms"] = timed(rescue_pipeline, 3)
+            ex["grind_blake3_factor20_ms"] = timed(lambda: crypto.grind_query_seed(crypto.Blake3_256, np.arange(32, dtype=np.uint8), 20), 3)
             # Merkle leaves/s (BLAKE3, 2^23 leaves)
             lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
             ms = timed(lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))
