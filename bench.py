@@ -125,6 +125,39 @@ def main():
             sharded = {"sharded_lde_commit_ms_2^20x%d_b8_blake3" % (4 * world): float(tt.item())}
         except Exception as e:  # never let the optional leg break the headline measurement
             sharded = {"sharded_lde_commit_error": repr(e)[:200]}
+        # FRI commit phase of a 2^24-point quadratic-extension LDE (configs[4]) sharded by row ranges: all-to-all re-stride
+        # + sub-root all-gather per layer, tail layers collapsed onto every rank
+        try:
+            from winterfell_amd import fri as wfri, parallel
+
+            class _Chan:
+                def __init__(self):
+                    self.k = 0
+
+                def commit_fri_layer(self, root):
+                    self.k += 1
+
+                def draw_fri_alpha(self):
+                    return np.array([fields.new(12345 + self.k), fields.new(777 + self.k)], dtype=np.uint64)
+
+            piece = ctx.to_device(np.random.default_rng(100 + rank).integers(0, fields.M, ((1 << 24) // world) * 2, dtype=np.uint64))
+            fopts = wfri.FriOptions(8, 4, 31)
+            fbackend = parallel.HipFriBackend(crypto.Blake3_256, fields.f64, 2, ctx)
+            run = lambda: parallel.sharded_fri_build_layers(fbackend, fopts, _Chan(), piece, 2, min_rows_per_rank=1 << 12)
+            run()
+            ts = []
+            for _ in range(3):
+                barrier()
+                t1 = time.perf_counter()
+                run()
+                barrier()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            tt = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded["sharded_fri_build_layers_ms_2^24_quad_fold4_blake3"] = float(tt.item())
+            del piece
+        except Exception as e:
+            sharded["sharded_fri_error"] = repr(e)[:200]
 
     if rank == 0:
         # ---- roofline: per-kernel durations from HIP events on the launch stream (wf_prof_*) ----

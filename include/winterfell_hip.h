@@ -241,6 +241,14 @@ int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, c
 int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                      uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded);
 
+/* The same fold for `num_rows` consecutive rows, starting at row_start, of a layer whose full domain has 2^log_len
+ * points: d_transposed_rows holds only those rows, d_folded receives num_rows elements.  This is what one GPU runs on
+ * its contiguous row range when a FRI layer is sharded across devices (row i uses x_i = offset * g^i with the GLOBAL
+ * i, fri/src/folding/mod.rs:181-188); row_start = 0, num_rows = 2^log_len / folding is wf_fri_apply_drp. */
+int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
+                          uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
+                          const void *h_alpha, void *d_folded);
+
 #ifdef __cplusplus
 }
 #endif

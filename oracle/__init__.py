@@ -336,6 +336,17 @@ def apply_drp(transposed, N, domain_offset, alpha, D=1):
     return out
 
 
+def apply_drp_rows(transposed, N, domain_size, row_start, domain_offset, alpha, D=1):
+    """apply_drp for a contiguous range of rows of a layer with `domain_size` points (multi-GPU shard)."""
+    v = _u64arr(transposed)
+    rows = v.size // (N * D)
+    a = _u64arr(alpha)
+    out = np.empty(rows * D, dtype=np.uint64)
+    lib().or_apply_drp_rows(_ptr(v), _u64(rows), ctypes.c_uint(D), _u64(N), _u64(domain_size), _u64(row_start), _u64(domain_offset),
+                            _ptr(a), _ptr(out))
+    return out
+
+
 def fri_num_layers(domain_size, folding, blowup, remainder_max_degree):
     lib().or_fri_num_layers.restype = _u64
     return lib().or_fri_num_layers(_u64(domain_size), _u64(folding), _u64(blowup), _u64(remainder_max_degree))

@@ -43,16 +43,18 @@ int or_fri_layer_commit(int hasher, const uint64_t *transposed, uint64_t rows, u
     return or_merkle_build(hasher, leaves, rows, nodes);
 }
 
-/* apply_drp — fri/src/folding/mod.rs:86-118.  values: rows x N elements; result: rows elements. */
-void or_apply_drp(const uint64_t *values, uint64_t rows, unsigned D, uint64_t N, uint64_t domain_offset,
-                  const uint64_t *alpha, uint64_t *result) {
+/* apply_drp — fri/src/folding/mod.rs:86-118, for `rows` consecutive rows starting at row_start of a layer whose full
+ * domain has domain_size points (a shard of the layer; row_start = 0, rows = domain_size / N is the reference call).
+ * values: rows x N elements; result: rows elements. */
+void or_apply_drp_rows(const uint64_t *values, uint64_t rows, unsigned D, uint64_t N, uint64_t domain_size, uint64_t row_start,
+                       uint64_t domain_offset, const uint64_t *alpha, uint64_t *result) {
     /* get_inv_offsets — folding/mod.rs:181-188 */
-    uint64_t n = rows * N;
+    uint64_t n = domain_size;
     uint64_t g_inv = f64_inv(f64_root_of_unity((unsigned)__builtin_ctzll(n)));
     uint64_t *inv_tw = (uint64_t *)malloc((N / 2 ? N / 2 : 1) * 8);
     or_f64_get_inv_twiddles(inv_tw, N);
     uint64_t len_offset = f64_inv(f64_new((uint32_t)N));
-    uint64_t io = f64_inv(domain_offset); /* inv_offsets[0]; inv_offsets[i] = io * g_inv^i */
+    uint64_t io = f64_mul(f64_inv(domain_offset), f64_exp(g_inv, row_start)); /* inv_offsets[i] = offset^-1 * g_inv^i */
     uint64_t poly[16 * 3];
     for (uint64_t i = 0; i < rows; i++) {
         memcpy(poly, values + i * N * D, N * D * 8);
@@ -73,6 +75,11 @@ void or_apply_drp(const uint64_t *values, uint64_t rows, unsigned D, uint64_t N,
         io = f64_mul(io, g_inv);
     }
     free(inv_tw);
+}
+
+void or_apply_drp(const uint64_t *values, uint64_t rows, unsigned D, uint64_t N, uint64_t domain_offset,
+                  const uint64_t *alpha, uint64_t *result) {
+    or_apply_drp_rows(values, rows, D, N, rows * N, 0, domain_offset, alpha, result);
 }
 
 /* num_fri_layers — fri/src/options.rs:85-93 */

@@ -131,3 +131,41 @@ def test_full_size_fold_properties(wf, oracle):
         c = np.stack([(acc0 * scale) % P, (acc1 * scale) % P], axis=1)
     want = fields.from_ints(c[::-1].astype(np.uint64))
     assert np.array_equal(prover.remainder_poly, want)
+
+
+@pytest.mark.parametrize("world,hname,D,log_len,N", [(2, "Blake3_256", 2, 14, 4), (4, "Blake3_256", 1, 12, 2), (8, "Blake3_256", 2, 16, 4),
+                                                      (8, "Rp64_256", 3, 12, 8), (4, "Blake3_256", 2, 12, 16)])
+def test_sharded_fri_emulation_equals_single_device(wf, oracle, world, hname, D, log_len, N):
+    """SURVEY 8e layout (i) / BASELINE configs[4]: the FRI commit phase sharded by contiguous row ranges over G logical
+    ranks on one device (collectives by slicing; the same local kernels and index math as the torch.distributed path,
+    which tests/test_parallel_cpu.py runs under gloo) gives the single-device prover's roots, nodes, rows and remainder."""
+    ctx, crypto, fri, fields = wf
+    from winterfell_amd import parallel
+    hasher = getattr(crypto, hname)
+    hid = 0 if hname == "Blake3_256" else 1
+    blowup = 8
+    ev = ctx.to_device(_lde_of_random_poly(oracle, log_len, blowup, D, 5 * world + N))
+    opts = fri.FriOptions(blowup, N, 7)
+    ref_chan = oracle.ProverChannel(hid, D)
+    ref = fri.FriProver(opts, hasher, ext_degree=D)
+    ref.build_layers(ref_chan, ev.clone())
+    results, chans = parallel.emulated_sharded_fri(lambda: parallel.HipFriBackend(hasher, fields.f64, D, ctx), opts,
+                                                   lambda: oracle.ProverChannel(hid, D), ev, D, world)
+    nsh = len(results[0]["layers"])
+    assert nsh >= 1 and nsh + len(results[0]["tail"]) == ref.num_layers()
+    for r in range(world):
+        assert len(chans[r].commitments) == len(ref_chan.commitments)
+        assert all(np.array_equal(a, b) for a, b in zip(chans[r].commitments, ref_chan.commitments))
+        assert np.array_equal(results[r]["remainder"], ref.remainder_poly)
+    for k in range(nsh):
+        rows = ctx.to_host(ref.layers[k].evaluations)
+        per = rows.shape[0] // world
+        for r in range(world):
+            lay = results[r]["layers"][k]
+            assert lay["row_start"] == r * per
+            assert np.array_equal(ctx.to_host(lay["rows"]), rows[r * per:(r + 1) * per])
+        full = parallel.assemble_nodes(world, rows.shape[0], [ctx.to_host(results[r]["layers"][k]["nodes"]) for r in range(world)],
+                                       ctx.to_host(results[0]["layers"][k]["top"]))
+        assert np.array_equal(full, ref.layers[k].commitment.nodes)
+    for k, (trows, tnodes) in enumerate(results[0]["tail"]):
+        assert np.array_equal(tnodes, ref.layers[nsh + k].commitment.nodes)

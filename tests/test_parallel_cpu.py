@@ -92,3 +92,133 @@ def test_sharded_commit_equals_partitioned_single_process(oracle, tmp_path, worl
     # and it differs from the unpartitioned commitment (SURVEY 8e caveat)
     _, _, _, nodes1 = oracle.build_trace_commitment(hasher_id, trace, blowup, oracle.f64_new(7))
     assert not np.array_equal(nodes1[1], nodes[1])
+
+
+# ---- FRI commit phase sharded by contiguous row ranges (SURVEY 8e layout (i), BASELINE configs[4]) ---------------------
+class _OracleFriBackend:
+    def __init__(self, hasher_id, D):
+        import oracle
+        self.o, self.h, self.D = oracle, hasher_id, D
+
+    def commit_rows(self, chunk_major, folding):
+        import torch
+        o, D = self.o, self.D
+        buf = chunk_major.numpy()
+        rows = buf.size // (folding * D)
+        tr = o.transpose_slice(buf, folding, D).reshape(rows, folding * D)
+        if rows >= 2:
+            leaves, nodes = o.fri_layer_commit(self.h, tr.reshape(-1), folding, D)
+            return torch.from_numpy(tr), torch.from_numpy(leaves), torch.from_numpy(nodes)
+        leaves = np.stack([o.hash_elements(self.h, tr[0])])
+        return torch.from_numpy(tr), torch.from_numpy(leaves), torch.from_numpy(leaves.copy())
+
+    def fold_rows(self, rows_t, log_len, folding, row_start, offset_words, alpha):
+        import torch
+        out = self.o.apply_drp_rows(rows_t.numpy().reshape(-1), folding, 1 << log_len, row_start, int(offset_words[0]), alpha, self.D)
+        return torch.from_numpy(out)
+
+    def merkle_nodes(self, leaves):
+        import torch
+        if leaves.shape[0] == 1:
+            return leaves.clone()
+        return torch.from_numpy(self.o.merkle_build(self.h, leaves.numpy()))
+
+    def finish_unsharded(self, options, channel, vector):
+        return _oracle_fri(self.o, self.h, self.D, options, channel, vector.numpy().copy())
+
+
+def _oracle_fri(o, hid, D, options, channel, ev):
+    """The reference prover's layer loop (fri/src/prover/mod.rs:179-239) on the oracle; returns ([(rows, nodes)], remainder)."""
+    N, off = options.folding_factor, int(options.domain_offset())
+    length = ev.size // D
+    layers = []
+    for _ in range(options.num_fri_layers(length)):
+        tr = o.transpose_slice(ev, N, D)
+        leaves, nodes = o.fri_layer_commit(hid, tr, N, D)
+        channel.commit_fri_layer(nodes[1])
+        ev = o.apply_drp(tr, N, off, channel.draw_fri_alpha(), D)
+        layers.append((tr.reshape(length // N, N * D), nodes))
+        length //= N
+    rem, com = o.fri_remainder(hid, ev, off, options.blowup_factor, D)
+    channel.commit_fri_layer(com)
+    return layers, rem.reshape(-1, D)
+
+
+def _fri_case(world):
+    from conftest import rand_field
+    import oracle
+    from winterfell_amd.fri import FriOptions
+    D, log_len, blowup, N = 2, 12, 8, 4
+    n = (1 << log_len) // blowup
+    p = oracle.f64_from_int(rand_field(77, n * D))
+    ev = oracle.evaluate_poly_with_offset(p, oracle.f64_new(7), blowup, D=D, par=True)
+    return D, N, FriOptions(blowup, N, 7), ev
+
+
+def _fri_worker(rank, world, port, hasher_id, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from winterfell_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    D, N, opts, ev = _fri_case(world)
+    per = ev.size // world
+    piece = torch.from_numpy(ev[rank * per:(rank + 1) * per].copy())
+    chan = oracle.ProverChannel(hasher_id, D)
+    res = parallel.sharded_fri_build_layers(_OracleFriBackend(hasher_id, D), opts, chan, piece, D)
+    np.savez(os.path.join(out_dir, "fri%d.npz" % rank), nlayers=len(res["layers"]), remainder=res["remainder"],
+             commitments=np.stack(chan.commitments), ntail=len(res["tail"]),
+             **{"rows%d" % k: l["rows"].numpy() for k, l in enumerate(res["layers"])},
+             **{"nodes%d" % k: l["nodes"].numpy() for k, l in enumerate(res["layers"])},
+             **{"top%d" % k: l["top"].numpy() for k, l in enumerate(res["layers"])},
+             **{"tailnodes%d" % k: t[1] for k, t in enumerate(res["tail"])})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,hasher_id", [(2, 0), (4, 0), (2, 1)])
+def test_sharded_fri_equals_single_process(oracle, tmp_path, world, hasher_id):
+    """2^12 LDE domain, quadratic extension, folding 4, remainder degree 7: layers 2^12 -> 2^10 -> 2^8 -> 2^6 (remainder
+    2^6 / 8 = 8 coefficients).  Every layer root, every node, every transposed row and the remainder must equal the
+    single-process prover's; the first layers run sharded, the tail collapses onto every rank."""
+    import torch.multiprocessing as mp
+    from winterfell_amd import parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_fri_worker, args=(world, port, hasher_id, str(tmp_path)), nprocs=world, join=True)
+    D, N, opts, ev = _fri_case(world)
+    ochan = oracle.ProverChannel(hasher_id, D)
+    want_layers, want_rem = _oracle_fri(oracle, hasher_id, D, opts, ochan, ev.copy())
+    got = [np.load(os.path.join(str(tmp_path), "fri%d.npz" % r)) for r in range(world)]
+    nsh = int(got[0]["nlayers"])
+    assert nsh >= 2 and nsh + int(got[0]["ntail"]) == len(want_layers) == 3
+    for r in range(world):
+        assert np.array_equal(got[r]["commitments"], np.stack(ochan.commitments))      # same transcript on every rank
+        assert np.array_equal(got[r]["remainder"], want_rem)
+    for k in range(nsh):
+        rows, nodes = want_layers[k]
+        per = rows.shape[0] // world
+        for r in range(world):
+            assert np.array_equal(got[r]["rows%d" % k], rows[r * per:(r + 1) * per])
+        full = parallel.assemble_nodes(world, rows.shape[0], [g["nodes%d" % k] for g in got], got[0]["top%d" % k])
+        assert np.array_equal(full, nodes)
+    for k in range(int(got[0]["ntail"])):
+        assert np.array_equal(got[0]["tailnodes%d" % k], want_layers[nsh + k][1])
+
+
+def test_fri_restride_index_math():
+    """chunk (j, g) = e[(j*G + g) * rc/G ...]; its owner under contiguous pieces is floor((j*G + g) / N)."""
+    from winterfell_amd import parallel
+    for world, N, length in ((2, 4, 64), (4, 4, 64), (8, 4, 256), (8, 2, 64), (4, 16, 256)):
+        rc = length // N
+        per, chunk = length // world, rc // world
+        for g in range(world):
+            for j in range(N):
+                start = j * rc + g * chunk                       # first element of chunk (j, g): rows g*chunk.. of column j
+                assert start == (j * world + g) * chunk
+                assert start // per == parallel.fri_chunk_owner(j, g, world, N)
+                assert (start + chunk - 1) // per == start // per  # a chunk never straddles two pieces

@@ -52,6 +52,7 @@ _PROTOS = {
     "wf_deep_compose": [_vp, _int, _u32, _vp, _u32, _u64, _vp, _u32, _u64, _vp, _u32, _u64, _u32, _vp, _vp, _vp, _vp],
     "wf_fri_layer_commit": [_vp, _int, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "wf_fri_apply_drp": [_vp, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
+    "wf_fri_apply_drp_rows": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -34,14 +34,14 @@ struct FoldConsts {
 };
 
 template <class F, int LOG_NF, int D>
-__global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, typename F::T *out, uint32_t log_rc,
-                                                       const typename F::T *io_lo, const typename F::T *io_hi,
+__global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, typename F::T *out, uint64_t row_start,
+                                                       uint64_t num_rows, const typename F::T *io_lo, const typename F::T *io_hi,
                                                        uint32_t io_log_lo, const typename F::T *w16,
                                                        FoldConsts<typename F::T> cst) {
     typedef typename F::T T;
     constexpr int N = 1 << LOG_NF;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (1ull << log_rc)) return;
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // row within the shard
+    if (i >= num_rows) return;
     T comp[D][N];
 #pragma unroll
     for (int j = 0; j < N; j++)
@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, t
     // forward DFT per component (bit-reversed registers); inverse coefficient k = X[(N - k) mod N]
 #pragma unroll
     for (int d = 0; d < D; d++) dft_dif<F, LOG_NF>(comp[d], w16);
-    const T io = series_at<F>(io_lo, io_hi, io_log_lo, i);   // offset^-1 * g^-i
+    const T io = series_at<F>(io_lo, io_hi, io_log_lo, row_start + i);   // offset^-1 * g^-(global row)
     T scale[N];
     scale[0] = cst.inv_n;
 #pragma unroll
@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, t
 }
 
 template <class HF, int D>
-int launch_fold(wf_ctx *ctx, uint32_t log_nf, const void *t_, void *out_, uint32_t log_rc, const SeriesTable &io,
+int launch_fold(wf_ctx *ctx, uint32_t log_nf, const void *t_, void *out_, uint64_t row_start, uint64_t rc, const SeriesTable &io,
                 const FoldConsts<typename HF::T> &cst) {
     typedef typename HF::Dev F;
     typedef typename F::T T;
@@ -81,14 +81,13 @@ int launch_fold(wf_ctx *ctx, uint32_t log_nf, const void *t_, void *out_, uint32
     void *w256, *w16v;
     WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16v));
     const T *w16 = (const T *)w16v;
-    const uint64_t rc = 1ull << log_rc;
     const dim3 grid((uint32_t)((rc + 255) / 256)), block(256);
     wf_prof_begin(ctx, "fri_fold");
     switch (log_nf) {
-        case 1: hipLaunchKernelGGL((fri_fold_kernel<F, 1, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
-        case 2: hipLaunchKernelGGL((fri_fold_kernel<F, 2, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
-        case 3: hipLaunchKernelGGL((fri_fold_kernel<F, 3, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
-        default: hipLaunchKernelGGL((fri_fold_kernel<F, 4, D>), grid, block, 0, ctx->stream, t, out, log_rc, lo, hi, io.log_lo, w16, cst); break;
+        case 1: hipLaunchKernelGGL((fri_fold_kernel<F, 1, D>), grid, block, 0, ctx->stream, t, out, row_start, rc, lo, hi, io.log_lo, w16, cst); break;
+        case 2: hipLaunchKernelGGL((fri_fold_kernel<F, 2, D>), grid, block, 0, ctx->stream, t, out, row_start, rc, lo, hi, io.log_lo, w16, cst); break;
+        case 3: hipLaunchKernelGGL((fri_fold_kernel<F, 3, D>), grid, block, 0, ctx->stream, t, out, row_start, rc, lo, hi, io.log_lo, w16, cst); break;
+        default: hipLaunchKernelGGL((fri_fold_kernel<F, 4, D>), grid, block, 0, ctx->stream, t, out, row_start, rc, lo, hi, io.log_lo, w16, cst); break;
     }
     wf_prof_end(ctx);
     WF_HIP(hipGetLastError());
@@ -131,12 +130,14 @@ int layer_commit(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
 }
 
 template <class HF>
-int apply_drp(wf_ctx *ctx, uint32_t D, const void *d_transposed, uint32_t log_len, uint32_t folding, const void *h_domain_offset,
-              const void *h_alpha, void *d_folded) {
+int apply_drp(wf_ctx *ctx, uint32_t D, const void *d_transposed, uint32_t log_len, uint32_t folding, uint64_t row_start,
+              uint64_t num_rows, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
     typedef typename HF::T T;
     uint32_t log_nf;
     WF_TRY(check_args(HF::Dev::MAX_EXT, D, log_len, folding, &log_nf));
     const uint32_t log_rc = log_len - log_nf;
+    if (row_start + num_rows > (1ull << log_rc) || row_start + num_rows < row_start) return WF_ERR_INVALID_ARG;
+    if (num_rows == 0) return WF_OK;
     T off;
     WF_TRY(wf_load_offset<HF>(h_domain_offset, &off));
     // inv_offsets[i] = offset^-1 * (g^-1)^i, g = root of unity of the layer's domain (folding/mod.rs:181-188)
@@ -150,9 +151,9 @@ int apply_drp(wf_ctx *ctx, uint32_t D, const void *d_transposed, uint32_t log_le
         memcpy(&cst.alpha[d], (const uint8_t *)h_alpha + d * sizeof(T), sizeof(T));
         if (!HF::valid_internal(cst.alpha[d])) return WF_ERR_INVALID_ARG;
     }
-    if (D == 1) return launch_fold<HF, 1>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
-    if (D == 2) return launch_fold<HF, 2>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
-    if constexpr (HF::Dev::MAX_EXT >= 3) return launch_fold<HF, 3>(ctx, log_nf, d_transposed, d_folded, log_rc, io, cst);
+    if (D == 1) return launch_fold<HF, 1>(ctx, log_nf, d_transposed, d_folded, row_start, num_rows, io, cst);
+    if (D == 2) return launch_fold<HF, 2>(ctx, log_nf, d_transposed, d_folded, row_start, num_rows, io, cst);
+    if constexpr (HF::Dev::MAX_EXT >= 3) return launch_fold<HF, 3>(ctx, log_nf, d_transposed, d_folded, row_start, num_rows, io, cst);
     return WF_ERR_UNSUPPORTED;
 }
 
@@ -170,13 +171,23 @@ extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ex
     }
 }
 
-extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
-                                uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
-    if (!ctx || !d_transposed || !h_domain_offset || !h_alpha || !d_folded) return WF_ERR_INVALID_ARG;
+extern "C" int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
+                                     uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
+                                     const void *h_alpha, void *d_folded) {
+    if (!ctx || !d_transposed_rows || !h_domain_offset || !h_alpha || !d_folded) return WF_ERR_INVALID_ARG;
     switch (field) {
-        case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
-        case WF_FIELD_F128: return apply_drp<HostF128>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
-        case WF_FIELD_F62: return apply_drp<HostF62>(ctx, ext_degree, d_transposed, log_len, folding, h_domain_offset, h_alpha, d_folded);
+        case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, h_alpha, d_folded);
+        case WF_FIELD_F128: return apply_drp<HostF128>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, h_alpha, d_folded);
+        case WF_FIELD_F62: return apply_drp<HostF62>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, h_alpha, d_folded);
         default: return WF_ERR_UNSUPPORTED;
     }
+}
+
+extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
+                                uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
+    uint32_t log_nf = 0;
+    while ((1u << log_nf) < folding && log_nf < 5) log_nf++;
+    if (log_len < log_nf) return WF_ERR_INVALID_ARG;
+    return wf_fri_apply_drp_rows(ctx, field, ext_degree, d_transposed, log_len, folding, 0, 1ull << (log_len - log_nf), h_domain_offset,
+                                 h_alpha, d_folded);
 }

@@ -159,3 +159,226 @@ def emulated_sharded_commit(backend, trace_shards, domain):
     roots = torch.stack([nd[1] if per > 1 else nd[0] for _, nd in out])
     top = backend.merkle_nodes(roots)
     return dict(shards=locals_, per_rank=out, top=top, root=top[1] if world > 1 else roots[0])
+
+
+# ==== FRI commit phase sharded by contiguous row ranges (layout (i)) ===========================
+#
+# Layer vector e of `length` elements, rc = length / N rows; rank g owns rows [g*rc/G, (g+1)*rc/G) of the transposed
+# matrix t[i][j] = e[i + j*rc] (fri/src/prover/mod.rs:202-222, utils::transpose_slice) and the matching contiguous piece
+# of every vector.  Per layer:
+#   1. re-stride: rank g needs the N chunks e[(j*G + g) * rc/G ...] (length rc/G each); chunk (j, g) sits on rank
+#      floor((j*G + g) / N) because pieces are contiguous                                  (all-to-all, length/G elements per rank)
+#   2. local transpose + leaf hashes + subtree over the rank's rows                        (no communication)
+#   3. all-gather of the G sub-roots, top log2(G) levels on every rank, root -> channel -> alpha (every rank runs the same
+#      deterministic channel, so alpha needs no broadcast)
+#   4. fold the local rows with the GLOBAL row index in x_i = offset * g^i                 (no communication)
+# The folded piece is again the rank's contiguous piece of the next layer's vector.  Once a layer has fewer than
+# `min_rows_per_rank` rows per rank the pieces are all-gathered and every rank finishes the remaining (tiny) layers and the
+# remainder redundantly.  Roots, nodes, evaluations and the remainder are bit-identical to FriProver.build_layers on one
+# device (P = 1 proof format, fri/src/prover/mod.rs:289).
+
+def fri_chunk_owner(j, g, world, folding):
+    """rank holding chunk (j, g) of the layer vector when pieces are contiguous."""
+    return (j * world + g) // folding
+
+
+def fri_restride(piece, elem_words, world, rank, folding, group=None):
+    """piece: this rank's contiguous length/G elements (torch uint64, flat).  Returns the rank's chunk-major buffer
+    [folding][rc/G] (flat): element (j, i) = e[i0 + i + j*rc] with i0 = rank * rc/G."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return piece
+    per = piece.numel() // elem_words                # length / G
+    chunk = per // folding                           # rc / G elements
+    cw = chunk * elem_words
+    # what this rank sends to each destination g: its chunks (j, g), j ascending
+    send, in_split = [], []
+    for g in range(world):
+        cnt = 0
+        for j in range(folding):
+            if fri_chunk_owner(j, g, world, folding) == rank:
+                start = (j * world + g) * chunk - rank * per
+                send.append(piece[start * elem_words:(start + chunk) * elem_words])
+                cnt += 1
+        in_split.append(cnt * cw)
+    out_split = [sum(1 for j in range(folding) if fri_chunk_owner(j, rank, world, folding) == h) * cw for h in range(world)]
+    sendbuf = torch.cat(send) if send else piece[:0]
+    recv = torch.empty(folding * cw, dtype=piece.dtype, device=piece.device)
+    try:
+        # collectives move the words as int64 (uint64 is not a collective dtype for gloo / older RCCL builds)
+        dist.all_to_all_single(_i64(recv), _i64(sendbuf.contiguous()), out_split, in_split, group=group)
+    except (RuntimeError, NotImplementedError):
+        # backend without (uneven) all-to-all: all-gather the pieces and cut the chunks out (more bytes, same result)
+        full = _all_gather_cat(piece, world, group)
+        recv = torch.cat([full[(j * world + rank) * cw:(j * world + rank + 1) * cw] for j in range(folding)])
+    return recv
+
+
+class HipFriBackend:
+    """Local FRI steps on this rank's GPU through the C ABI."""
+
+    def __init__(self, hasher, field, ext_degree, ctx=None):
+        from ._lib import default_context
+        self.hasher, self.field, self.D, self.ctx = hasher, field, ext_degree, ctx or default_context()
+
+    def commit_rows(self, chunk_major, folding):
+        """chunk-major [N][rows] buffer -> (transposed rows [rows, N*D*W], leaves [rows, 32], subtree nodes [rows, 32])."""
+        import ctypes
+        from ._lib import ptr
+        f, D, ctx = self.field, self.D, self.ctx
+        ew = D * f.W
+        length = chunk_major.numel() // ew
+        rows = length // folding
+        tr, leaves = ctx.empty_u64(rows, folding * ew), ctx.empty_u8(rows, 32)
+        if rows >= 2:
+            nodes = ctx.empty_u8(rows, 32)
+            ctx.call("wf_fri_layer_commit", self.hasher.HASH_ID, f.ID, D, ptr(chunk_major), length.bit_length() - 1, folding,
+                     ptr(tr), ptr(leaves), ptr(nodes), None)
+            return tr, leaves, nodes
+        # a single row: the "vector" is the row itself; its leaf is its own subtree root
+        tr = chunk_major.reshape(1, -1).clone()
+        ctx.call("wf_hash_elements_batch", self.hasher.HASH_ID, f.ID, ptr(tr), 1, folding * D, folding * D, ptr(leaves))
+        return tr, leaves, leaves.clone()
+
+    def fold_rows(self, rows_t, log_len, folding, row_start, offset_words, alpha):
+        import ctypes
+        from ._lib import ptr
+        f, D, ctx = self.field, self.D, self.ctx
+        n = rows_t.shape[0]
+        out = ctx.empty_u64(n * D * f.W)
+        a = np.ascontiguousarray(alpha, dtype=np.uint64)
+        ctx.call("wf_fri_apply_drp_rows", f.ID, D, ptr(rows_t), log_len, folding, row_start, n, offset_words.ctypes.data_as(ctypes.c_void_p),
+                 a.ctypes.data_as(ctypes.c_void_p), ptr(out))
+        return out
+
+    def merkle_nodes(self, leaves):
+        from ._lib import ptr
+        n = leaves.shape[0]
+        if n == 1:
+            return leaves.clone()
+        nodes = self.ctx.empty_u8(n, 32)
+        self.ctx.call("wf_merkle_build", self.hasher.HASH_ID, ptr(leaves.contiguous()), n, ptr(nodes))
+        return nodes
+
+    def finish_unsharded(self, options, channel, vector):
+        """remaining layers + remainder on one device: FriProver.build_layers on the gathered vector."""
+        from .fri.prover import FriProver
+        p = FriProver(options, self.hasher, self.D, self.ctx)
+        p.build_layers(channel, vector)
+        return [(self.ctx.to_host(l.evaluations), l.commitment.nodes) for l in p.layers], p.remainder_poly
+
+
+def sharded_fri_build_layers(backend, options, channel, piece, ext_degree, world=None, rank=None, group=None, min_rows_per_rank=2,
+                             exchange=None, gather=None):
+    """FriProver::build_layers with every layer sharded by contiguous row ranges.
+
+    piece: this rank's contiguous 1/G of the LDE evaluations (flat uint64 tensor).  channel: the host Fiat-Shamir channel
+    (one identical instance per rank).  Returns dict(layers=[dict(rows, nodes, top, root, row_start, sharded)], tail=[(rows,
+    nodes)] for the layers finished unsharded, remainder)."""
+    import torch
+    import torch.distributed as dist
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    exchange = exchange or (lambda p, ew, N: fri_restride(p, ew, world, rank, N, group))
+    gather = gather or (lambda t: _all_gather_cat(t, world, group))
+    f, N = options.field, options.folding_factor
+    ew = ext_degree * f.W
+    off = f.element_words(int(options.domain_offset()))
+    length = piece.numel() // ew * world
+    total_layers = options.num_fri_layers(length)
+    layers = []
+    while len(layers) < total_layers and (length // N) // world >= min_rows_per_rank and (length // N) % world == 0:
+        rc = length // N
+        rows_local = rc // world
+        buf = exchange(piece, ew, N)
+        rows_t, leaves, nodes = backend.commit_rows(buf, N)
+        sub_root = nodes[1] if rows_local > 1 else leaves[0]
+        roots = gather(sub_root.reshape(1, 32)).reshape(world, 32) if world > 1 else sub_root.reshape(1, 32)
+        top = backend.merkle_nodes(roots) if world > 1 else None
+        root = top[1] if world > 1 else sub_root
+        root_h = root.cpu().numpy() if hasattr(root, "cpu") else np.asarray(root)
+        channel.commit_fri_layer(root_h)
+        alpha = channel.draw_fri_alpha()
+        piece = backend.fold_rows(rows_t, length.bit_length() - 1, N, rank * rows_local, off, alpha)
+        layers.append(dict(rows=rows_t, nodes=nodes, leaves=leaves, top=top, root=root_h, row_start=rank * rows_local))
+        length = rc
+    vector = gather(piece) if world > 1 else piece
+    tail_opts = _TailOptions(options, total_layers - len(layers))
+    tail, remainder = backend.finish_unsharded(tail_opts, channel, vector)
+    return dict(layers=layers, tail=tail, remainder=remainder)
+
+
+class _TailOptions:
+    """FriOptions view that fixes the number of remaining layers (the unsharded tail must not re-derive it from a
+    domain size that already shrank)."""
+
+    def __init__(self, options, num_layers):
+        self._o, self._n = options, num_layers
+        self.field, self.blowup_factor, self.folding_factor = options.field, options.blowup_factor, options.folding_factor
+        self.remainder_max_degree = options.remainder_max_degree
+
+    def domain_offset(self):
+        return self._o.domain_offset()
+
+    def num_fri_layers(self, domain_size):
+        return self._n
+
+
+def _i64(t):
+    import torch
+    return t.view(torch.int64) if t.dtype == torch.uint64 else t
+
+
+def _all_gather_cat(t, world, group=None):
+    import torch
+    import torch.distributed as dist
+    t = t.contiguous()
+    bufs = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather([_i64(b) for b in bufs], _i64(t), group=group)
+    return torch.cat(bufs)
+
+
+def emulated_sharded_fri(backends_factory, options, channel_factory, evaluations, ext_degree, world, min_rows_per_rank=2):
+    """Run the G-way sharded FRI commit phase on ONE device: G logical ranks advance layer by layer in lock step and the
+    collectives are done by slicing (used where only one GPU is reachable and by the emulation tests).  Returns the list
+    of per-rank results of `sharded_fri_build_layers`."""
+    import torch
+    f = options.field
+    ew = ext_degree * f.W
+    N = options.folding_factor
+    length = evaluations.numel() // ew
+    pieces = [evaluations.reshape(-1)[r * (length // world) * ew:(r + 1) * (length // world) * ew].clone() for r in range(world)]
+    backend = backends_factory()
+    channels = [channel_factory() for _ in range(world)]
+    total_layers = options.num_fri_layers(length)
+    off = f.element_words(int(options.domain_offset()))
+    results = [dict(layers=[]) for _ in range(world)]
+    done = 0
+    while done < total_layers and (length // N) // world >= min_rows_per_rank and (length // N) % world == 0:
+        rc = length // N
+        rows_local = rc // world
+        full = torch.cat(pieces)
+        cw = (rc // world) * ew
+        committed = []
+        for r in range(world):
+            buf = torch.cat([full[(j * world + r) * cw:(j * world + r + 1) * cw] for j in range(N)])
+            committed.append(backend.commit_rows(buf, N))
+        roots = torch.stack([(c[2][1] if rows_local > 1 else c[1][0]) for c in committed])
+        top = backend.merkle_nodes(roots) if world > 1 else None
+        root = top[1] if world > 1 else roots[0]
+        root_h = root.cpu().numpy() if hasattr(root, "cpu") else np.asarray(root)
+        new_pieces = []
+        for r in range(world):
+            channels[r].commit_fri_layer(root_h)
+            alpha = channels[r].draw_fri_alpha()
+            rows_t, leaves, nodes = committed[r]
+            new_pieces.append(backend.fold_rows(rows_t, length.bit_length() - 1, N, r * rows_local, off, alpha))
+            results[r]["layers"].append(dict(rows=rows_t, nodes=nodes, leaves=leaves, top=top, root=root_h, row_start=r * rows_local))
+        pieces, length, done = new_pieces, rc, done + 1
+    vector = torch.cat(pieces)
+    for r in range(world):
+        tail, rem = backend.finish_unsharded(_TailOptions(options, total_layers - done), channels[r], vector.clone())
+        results[r]["tail"], results[r]["remainder"] = tail, rem
+    return results, channels
