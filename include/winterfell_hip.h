@@ -51,7 +51,7 @@ enum {
 
 /* ---- enums ----------------------------------------------------------------------------------------- */
 enum { WF_FIELD_F64 = 0, WF_FIELD_F128 = 1, WF_FIELD_F62 = 2 };   /* math/src/field/{f64,f128,f62}       */
-enum { WF_HASH_BLAKE3_256 = 0, WF_HASH_RP64_256 = 1 };            /* crypto/src/hash/{blake,rescue/rp64_256} */
+enum { WF_HASH_BLAKE3_256 = 0, WF_HASH_RP64_256 = 1, WF_HASH_SHA3_256 = 2 };   /* crypto/src/hash/{blake,rescue/rp64_256,sha} */
 
 /* ---- context / memory ------------------------------------------------------------------------------ */
 int wf_version(void);

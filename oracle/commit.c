@@ -15,7 +15,7 @@
  *   air/src/options.rs:428-444                    PartitionOptions::{partition_size, num_partitions}
  *   prover/src/trace/trace_lde/default/mod.rs:245-282  build_trace_commitment
  *
- * Hasher ids: 0 = Blake3_256<f64>, 1 = Rp64_256.  A digest is 32 bytes in memory: raw bytes for
+ * Hasher ids: 0 = Blake3_256<f64>, 1 = Rp64_256, 2 = Sha3_256<f64> (sha/mod.rs:21-66).  A digest is 32 bytes in memory: raw bytes for
  * Blake3, four Montgomery-form words for Rp64_256 (rp64_256/digest.rs:16).
  */
 #include <stdint.h>
@@ -39,7 +39,16 @@ void or_f64_evaluate_poly_with_offset(const uint64_t *p, uint64_t n, unsigned D,
 void or_f64_evaluate_poly_with_offset_par(const uint64_t *p, uint64_t n, unsigned D, const uint64_t *twiddles,
                                           uint64_t domain_offset, uint64_t blowup, uint64_t *result);
 
-enum { H_BLAKE3_F64 = 0, H_RP64 = 1 };
+void or_sha3_256(const uint8_t *in, uint64_t len, uint8_t out[32]);
+
+enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2 };
+
+/* the byte hash behind a ByteDigest hasher: Blake3_256 (blake/mod.rs) or Sha3_256 (sha/mod.rs) — the two hashers have
+ * the same structure (hash of bytes / concatenated digests / seed || int / canonical element bytes) */
+void or_bytes_hash(int hasher, const uint8_t *in, uint64_t len, uint8_t out[32]) {
+    if (hasher == H_SHA3_F64) or_sha3_256(in, len, out);
+    else or_blake3_hash(in, len, out);
+}
 
 /* ---------------------------------------------------------------------------------------------- */
 /* Hasher / ElementHasher                                                                         */
@@ -53,7 +62,7 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
         uint64_t stackbuf[256] = {0};
         uint64_t *buf = n <= 256 ? stackbuf : (uint64_t *)malloc(n * 8);
         for (uint64_t i = 0; i < n; i++) buf[i] = f64_as_int(elems[i]);
-        or_blake3_hash((const uint8_t *)buf, n * 8, digest);
+        or_bytes_hash(hasher, (const uint8_t *)buf, n * 8, digest);
         if (buf != stackbuf) free(buf);
     }
 }
@@ -61,13 +70,13 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
 /* merge — blake/mod.rs:33-35, rp64_256/mod.rs:181-192 */
 void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_merge((const uint64_t *)two, (uint64_t *)digest);
-    else or_blake3_hash(two, 64, digest);
+    else or_bytes_hash(hasher, two, 64, digest);
 }
 
 /* merge_many — blake/mod.rs:37-39 (hash of concatenated bytes), rp64_256/mod.rs:194-196 */
 void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);
-    else or_blake3_hash(digests, 32 * k, digest);
+    else or_bytes_hash(hasher, digests, 32 * k, digest);
 }
 
 /* merge_with_int — blake/mod.rs:41-46, rp64_256/mod.rs:198-219 */
@@ -78,7 +87,7 @@ void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, 
         uint8_t data[40];
         memcpy(data, seed, 32);
         memcpy(data + 32, &value, 8);
-        or_blake3_hash(data, 40, digest);
+        or_bytes_hash(hasher, data, 40, digest);
     }
 }
 

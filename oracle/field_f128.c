@@ -1,6 +1,7 @@
 /* ORACLE — TEST INFRASTRUCTURE ONLY.  f128 instantiation of field_tmpl.inc (math/src/field/f128/mod.rs). */
 #include "f128.h"
 void or_blake3_hash(const uint8_t *in, uint64_t len, uint8_t out[32]);
+void or_bytes_hash(int hasher, const uint8_t *in, uint64_t len, uint8_t out[32]);
 
 #define FE u128
 #define FN(name) or_f128_##name
@@ -19,8 +20,7 @@ static inline void f128_extD_mul(unsigned D, const u128 *a, const u128 *b, u128 
 /* Blake3_256<f128>::hash_elements: IS_CANONICAL => raw element bytes (crypto/src/hash/blake/mod.rs:53-57);
  * Rp64_256 is only defined over f64. */
 static inline void f128_hash_elems(int hasher, const u128 *e, uint64_t n, uint8_t *digest) {
-    (void)hasher;
-    or_blake3_hash((const uint8_t *)e, n * 16, digest);
+    or_bytes_hash(hasher, (const uint8_t *)e, n * 16, digest);
 }
 #define F_HASH_ELEMS f128_hash_elems
 #include "field_tmpl.inc"

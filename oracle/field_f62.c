@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include "f62.h"
 void or_blake3_hash(const uint8_t *in, uint64_t len, uint8_t out[32]);
+void or_bytes_hash(int hasher, const uint8_t *in, uint64_t len, uint8_t out[32]);
 
 #define FE uint64_t
 #define FN(name) or_f62_##name
@@ -30,11 +31,10 @@ static inline void f62_extD_mul(unsigned D, const uint64_t *a, const uint64_t *b
 #define F_EXT_MUL f62_extD_mul
 /* Blake3_256<f62>::hash_elements: not IS_CANONICAL => canonical little-endian bytes of as_int() (blake/mod.rs:58-64) */
 static inline void f62_hash_elems(int hasher, const uint64_t *e, uint64_t n, uint8_t *digest) {
-    (void)hasher;
     uint64_t stackbuf[768];
     uint64_t *buf = n <= 768 ? stackbuf : (uint64_t *)malloc(n * 8);
     for (uint64_t i = 0; i < n; i++) buf[i] = f62_as_int(e[i]);
-    or_blake3_hash((const uint8_t *)buf, n * 8, digest);
+    or_bytes_hash(hasher, (const uint8_t *)buf, n * 8, digest);
     if (buf != stackbuf) free(buf);
 }
 #define F_HASH_ELEMS f62_hash_elems

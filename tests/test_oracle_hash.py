@@ -118,3 +118,33 @@ def test_merkle_errors_and_concurrent(oracle):
         if hasher == 1:
             lv = oracle.f64_from_int(splitmix64(9, n * 4)).view(np.uint8).reshape(n, 32)
         assert np.array_equal(oracle.merkle_build(hasher, lv, par=True), oracle.merkle_build(hasher, lv))
+
+
+def test_sha3_256_pinned_to_hashlib(oracle):
+    """The reference's Sha3_256 hasher wraps the `sha3` crate (crypto/src/hash/sha/mod.rs:21-66, not vendored); the
+    oracle restates FIPS 202 and is pinned here against Python's independent implementation, through the raw byte hash
+    and through every Hasher entry point of hasher id 2."""
+    import ctypes
+    import hashlib
+    lib = oracle.lib()
+
+    def sha3(b):
+        out = np.empty(32, dtype=np.uint8)
+        a = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(1, dtype=np.uint8)
+        lib.or_sha3_256(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(b)), out.ctypes.data_as(ctypes.c_void_p))
+        return out.tobytes()
+
+    for n in (0, 1, 7, 8, 31, 32, 40, 64, 135, 136, 137, 271, 272, 273, 1000, 4097):
+        b = bytes((i * 7 + 3) & 255 for i in range(n))
+        assert sha3(b) == hashlib.sha3_256(b).digest(), n
+    assert sha3(b"") == bytes.fromhex("a7ffc6f8bf1ed76651c14756a061d662f580ff4de43b49fa82d80a4b80f8434a")   # FIPS 202 KAT
+    assert sha3(b"abc") == bytes.fromhex("3a985da74fe225b2045c172d6bd390bd855f086e3e9d525b46bfe24511431532")
+    ints = np.arange(1, 40, dtype=np.uint64)
+    el = oracle.f64_from_int(ints)
+    assert oracle.hash_elements(2, el).tobytes() == hashlib.sha3_256(ints.tobytes()).digest()      # canonical LE bytes
+    two = np.arange(64, dtype=np.uint8).reshape(2, 32)
+    assert oracle.merge(2, two).tobytes() == hashlib.sha3_256(two.tobytes()).digest()
+    assert oracle.merge_with_int(2, two[0], 0x0102030405060708).tobytes() == \
+        hashlib.sha3_256(two[0].tobytes() + (0x0102030405060708).to_bytes(8, "little")).digest()
+    many = np.arange(96, dtype=np.uint8).reshape(3, 32)
+    assert oracle.merge_many(2, many).tobytes() == hashlib.sha3_256(many.tobytes()).digest()

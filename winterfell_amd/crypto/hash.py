@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, default_context, ptr
+from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, default_context, ptr
 from ..math import fields
 
 
@@ -69,6 +69,11 @@ class _Hasher:
 class Blake3_256(_Hasher):
     """crypto::hash::Blake3_256<f64::BaseElement> (crypto/src/hash/blake/mod.rs:24-66)."""
     HASH_ID = WF_HASH_BLAKE3_256
+
+
+class Sha3_256(_Hasher):
+    """crypto::hash::Sha3_256<B> (crypto/src/hash/sha/mod.rs:21-66); ByteDigest<32>, same call structure as Blake3_256."""
+    HASH_ID = WF_HASH_SHA3_256
 
 
 class Rp64_256(_Hasher):

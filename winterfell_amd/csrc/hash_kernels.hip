@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include "blake3.cuh"
+#include "keccak.cuh"
 #include "fields.cuh"
 #include "rp64.cuh"
 #include "wf_internal.h"
@@ -29,6 +30,7 @@ struct HBlake3 {
     static constexpr uint32_t STAGE_LEVELS = 10;
     static const char *row_name() { return "hash_rows_blake3"; }
     static const char *merkle_name() { return "merkle_stage_blake3"; }
+    static const char *grind_name() { return "grind_blake3"; }
     static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) { b3::merge(in, out); }
     // merge_with_int (blake/mod.rs:41-46): hash of the 40 bytes seed || value.to_le_bytes() — one block
     static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
@@ -59,12 +61,53 @@ struct HBlake3 {
     }
 };
 
+// Sha3_256<B> (crypto/src/hash/sha/mod.rs:21-66): same byte-level structure as Blake3_256 with SHA3-256 as the byte hash
+struct HSha3 {
+    static constexpr uint32_t STAGE_LEVELS = 8;
+    static const char *row_name() { return "hash_rows_sha3"; }
+    static const char *merkle_name() { return "merkle_stage_sha3"; }
+    static const char *grind_name() { return "grind_sha3"; }
+    static __device__ __forceinline__ void put(const uint64_t (&d)[4], uint32_t (&out)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto w = [&](uint32_t i) -> uint64_t { return (uint64_t)in[2 * i] | ((uint64_t)in[2 * i + 1] << 32); };
+        k3::sha3_256_words(w, 8, d);
+        put(d, out);
+    }
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto w = [&](uint32_t i) -> uint64_t { return i < 4 ? ((uint64_t)seed[2 * i] | ((uint64_t)seed[2 * i + 1] << 32)) : value; };
+        k3::sha3_256_words(w, 5, d);
+        put(d, out);
+    }
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) { return (uint64_t)d[0] | ((uint64_t)d[1] << 32); }
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto w = [&](uint32_t i) -> uint64_t {
+            uint64_t v = p[i];
+            if (MODE == MODE_F64_CANON) v = gl::to_int(v);
+            else if (MODE == MODE_F62_CANON) v = f62::mul(f62::norm(v), 1);
+            return v;
+        };
+        k3::sha3_256_words(w, nelem, d);
+        put(d, out);
+    }
+};
+
 struct HRp64 {
     // a Rescue merge is ~6400 modmuls (0.2 ms of one wave): the nearly empty upper levels of a multi-level workgroup
     // would serialise ten such latencies per workgroup, so the tree is built one full-width level per launch
     static constexpr uint32_t STAGE_LEVELS = 1;
     static const char *row_name() { return "hash_rows_rp64"; }
     static const char *merkle_name() { return "merkle_stage_rp64"; }
+    static const char *grind_name() { return "grind_rp64"; }
     static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
         uint64_t two[8], d[4];
 #pragma unroll
@@ -307,7 +350,20 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
     return WF_OK;
 }
 
-int check_hash(int hash) { return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256) ? WF_OK : WF_ERR_UNSUPPORTED; }
+int check_hash(int hash) {
+    return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256 || hash == WF_HASH_SHA3_256) ? WF_OK : WF_ERR_UNSUPPORTED;
+}
+
+// run fn(H{}) with the hasher policy selected by `hash`
+template <class FN>
+int with_hasher(int hash, FN &&fn) {
+    switch (hash) {
+        case WF_HASH_BLAKE3_256: return fn(HBlake3{});
+        case WF_HASH_RP64_256: return fn(HRp64{});
+        case WF_HASH_SHA3_256: return fn(HSha3{});
+        default: return WF_ERR_UNSUPPORTED;
+    }
+}
 
 }  // namespace
 
@@ -316,8 +372,7 @@ extern "C" int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint
     WF_TRY(check_hash(hash));
     if (num_leaves < 2) return WF_ERR_TOO_FEW_LEAVES;
     if (num_leaves & (num_leaves - 1)) return WF_ERR_NOT_POWER_OF_TWO;
-    return hash == WF_HASH_BLAKE3_256 ? launch_merkle<HBlake3>(ctx, d_leaves, num_leaves, d_nodes)
-                                      : launch_merkle<HRp64>(ctx, d_leaves, num_leaves, d_nodes);
+    return with_hasher(hash, [&](auto h) { return launch_merkle<decltype(h)>(ctx, d_leaves, num_leaves, d_nodes); });
 }
 
 extern "C" int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t count, void *d_out) {
@@ -326,10 +381,10 @@ extern "C" int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, u
     if (count == 0) return WF_OK;
     const uint64_t blocks = (count + 255) / 256;
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
-    if (hash == WF_HASH_BLAKE3_256)
-        hipLaunchKernelGGL(merge_batch_kernel<HBlake3>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
-    else
-        hipLaunchKernelGGL(merge_batch_kernel<HRp64>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        hipLaunchKernelGGL(merge_batch_kernel<decltype(h)>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
+        return (int)WF_OK;
+    }));
     WF_HIP(hipGetLastError());
     return WF_OK;
 }
@@ -360,21 +415,20 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
         if (ps < min_ps) ps = min_ps;
     }
     if (ps >= num_cols) {
-        return hash == WF_HASH_BLAKE3_256
-                   ? launch_hash_rows<HBlake3>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves)
-                   : launch_hash_rows<HRp64>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves);
+        return with_hasher(hash, [&](auto h) {
+            return launch_hash_rows<decltype(h)>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves);
+        });
     }
     const uint32_t parts = (num_cols + ps - 1) / ps;
     void *tmp;
     WF_TRY(wf_scratch(ctx, 2, (size_t)num_rows * parts * 32, &tmp));
     // partition digests, then leaf = merge_many(partition digests): Blake3 hashes the raw digest bytes
     // (blake/mod.rs:37-39), Rp64_256 hashes the digests' 4*parts elements (rp64_256/mod.rs:194-196).
-    if (hash == WF_HASH_BLAKE3_256) {
-        WF_TRY(launch_hash_rows<HBlake3>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
-        return launch_hash_rows<HBlake3>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
-    }
-    WF_TRY(launch_hash_rows<HRp64>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
-    return launch_hash_rows<HRp64>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
+    return with_hasher(hash, [&](auto h) {
+        typedef decltype(h) H;
+        WF_TRY(launch_hash_rows<H>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
+        return launch_hash_rows<H>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
+    });
 }
 
 extern "C" int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_rows, uint64_t num_rows,
@@ -396,9 +450,9 @@ extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_dig
     if (count == 0) return WF_OK;
     // Blake3: hash of the concatenated digest bytes (blake/mod.rs:37-39); Rp64_256: hash_elements over the 4*k digest
     // elements (rp64_256/mod.rs:194-196).  Both are "raw words" for the row kernel.
-    return hash == WF_HASH_BLAKE3_256
-               ? launch_hash_rows<HBlake3>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out)
-               : launch_hash_rows<HRp64>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out);
+    return with_hasher(hash, [&](auto h) {
+        return launch_hash_rows<decltype(h)>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out);
+    });
 }
 
 extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h_seed, uint64_t first_value, uint64_t count,
@@ -411,10 +465,10 @@ extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
     Seed seed;
     memcpy(seed.w, h_seed, 32);
-    if (hash == WF_HASH_BLAKE3_256)
-        hipLaunchKernelGGL(merge_with_int_kernel<HBlake3>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
-    else
-        hipLaunchKernelGGL(merge_with_int_kernel<HRp64>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        hipLaunchKernelGGL(merge_with_int_kernel<decltype(h)>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
+        return (int)WF_OK;
+    }));
     WF_HIP(hipGetLastError());
     return WF_OK;
 }
@@ -433,20 +487,21 @@ extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grin
     if (lg < 16) lg = 16;
     if (lg > 24) lg = 24;
     if (hash == WF_HASH_RP64_256 && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
+    if (hash == WF_HASH_SHA3_256 && lg > 23) lg = 23;
     const uint64_t batch = 1ull << lg;
     uint64_t first = first_nonce;
     for (;;) {
         const uint64_t left = max_nonce - first;               // nonces first .. max_nonce inclusive = left + 1
         const uint64_t count = left < batch - 1 ? left + 1 : batch;
         WF_HIP(hipMemsetAsync(d_best, 0xff, 8, ctx->stream));
-        wf_prof_begin(ctx, hash == WF_HASH_BLAKE3_256 ? "grind_blake3" : "grind_rp64");
-        if (hash == WF_HASH_BLAKE3_256)
-            hipLaunchKernelGGL(grind_kernel<HBlake3>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, seed, first,
-                               count, grinding_factor, d_best);
-        else
-            hipLaunchKernelGGL(grind_kernel<HRp64>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, seed, first,
-                               count, grinding_factor, d_best);
-        wf_prof_end(ctx);
+        WF_TRY(with_hasher(hash, [&](auto h) {
+            typedef decltype(h) H;
+            wf_prof_begin(ctx, H::grind_name());
+            hipLaunchKernelGGL(grind_kernel<H>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, seed, first, count,
+                               grinding_factor, d_best);
+            wf_prof_end(ctx);
+            return (int)WF_OK;
+        }));
         WF_HIP(hipGetLastError());
         unsigned long long best;
         WF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
