@@ -51,7 +51,12 @@ enum {
 
 /* ---- enums ----------------------------------------------------------------------------------------- */
 enum { WF_FIELD_F64 = 0, WF_FIELD_F128 = 1, WF_FIELD_F62 = 2 };   /* math/src/field/{f64,f128,f62}       */
-enum { WF_HASH_BLAKE3_256 = 0, WF_HASH_RP64_256 = 1, WF_HASH_SHA3_256 = 2 };   /* crypto/src/hash/{blake,rescue/rp64_256,sha} */
+enum {                                   /* crypto/src/hash/... */
+    WF_HASH_BLAKE3_256 = 0,              /* blake/mod.rs:24-66                                  */
+    WF_HASH_RP64_256 = 1,                /* rescue/rp64_256/mod.rs (f64 only)                   */
+    WF_HASH_SHA3_256 = 2,                /* sha/mod.rs:21-66                                    */
+    WF_HASH_RPJIVE64_256 = 3             /* rescue/rp64_256_jive/mod.rs (f64 only, Jive 2-to-1) */
+};
 
 /* ---- context / memory ------------------------------------------------------------------------------ */
 int wf_version(void);

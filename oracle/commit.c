@@ -15,7 +15,7 @@
  *   air/src/options.rs:428-444                    PartitionOptions::{partition_size, num_partitions}
  *   prover/src/trace/trace_lde/default/mod.rs:245-282  build_trace_commitment
  *
- * Hasher ids: 0 = Blake3_256<f64>, 1 = Rp64_256, 2 = Sha3_256<f64> (sha/mod.rs:21-66).  A digest is 32 bytes in memory: raw bytes for
+ * Hasher ids: 0 = Blake3_256<f64>, 1 = Rp64_256, 2 = Sha3_256<f64> (sha/mod.rs:21-66), 3 = RpJive64_256 (rpjive64.c).  A digest is 32 bytes in memory: raw bytes for
  * Blake3, four Montgomery-form words for Rp64_256 (rp64_256/digest.rs:16).
  */
 #include <stdint.h>
@@ -41,7 +41,11 @@ void or_f64_evaluate_poly_with_offset_par(const uint64_t *p, uint64_t n, unsigne
 
 void or_sha3_256(const uint8_t *in, uint64_t len, uint8_t out[32]);
 
-enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2 };
+void or_rpjive_hash_elements(const uint64_t *e, uint64_t n, uint64_t digest[4]);
+void or_rpjive_merge(const uint64_t two[8], uint64_t digest[4]);
+void or_rpjive_merge_with_int(const uint64_t seed[4], uint64_t value, uint64_t digest[4]);
+
+enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2, H_RPJIVE64 = 3 };
 
 /* the byte hash behind a ByteDigest hasher: Blake3_256 (blake/mod.rs) or Sha3_256 (sha/mod.rs) — the two hashers have
  * the same structure (hash of bytes / concatenated digests / seed || int / canonical element bytes) */
@@ -57,6 +61,8 @@ void or_bytes_hash(int hasher, const uint8_t *in, uint64_t len, uint8_t out[32])
 void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t digest[32]) {
     if (hasher == H_RP64) {
         or_rp64_hash_elements(elems, n, (uint64_t *)digest);
+    } else if (hasher == H_RPJIVE64) {
+        or_rpjive_hash_elements(elems, n, (uint64_t *)digest);
     } else {
         /* blake/mod.rs:58-64: BlakeHasher.write_many -> as_int().to_le_bytes() per element */
         uint64_t stackbuf[256] = {0};
@@ -70,12 +76,14 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
 /* merge — blake/mod.rs:33-35, rp64_256/mod.rs:181-192 */
 void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_merge((const uint64_t *)two, (uint64_t *)digest);
+    else if (hasher == H_RPJIVE64) or_rpjive_merge((const uint64_t *)two, (uint64_t *)digest);
     else or_bytes_hash(hasher, two, 64, digest);
 }
 
 /* merge_many — blake/mod.rs:37-39 (hash of concatenated bytes), rp64_256/mod.rs:194-196 */
 void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);
+    else if (hasher == H_RPJIVE64) or_rpjive_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);  /* mod.rs:219-221 */
     else or_bytes_hash(hasher, digests, 32 * k, digest);
 }
 
@@ -83,6 +91,8 @@ void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t 
 void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, uint8_t digest[32]) {
     if (hasher == H_RP64) {
         or_rp64_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
+    } else if (hasher == H_RPJIVE64) {
+        or_rpjive_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
     } else {
         uint8_t data[40];
         memcpy(data, seed, 32);

@@ -129,7 +129,7 @@ int or_coin_draw(or_coin *c, unsigned D, uint64_t *out) {
         uint8_t d[32], bytes[32];
         c->counter += 1;
         or_hash_merge_with_int(c->hasher, c->seed, c->counter, d);
-        if (c->hasher == 1) or_rp64_digest_as_bytes((const uint64_t *)d, bytes); /* Digest::as_bytes */
+        if (c->hasher == 1 || c->hasher == 3) or_rp64_digest_as_bytes((const uint64_t *)d, bytes); /* Digest::as_bytes */
         else memcpy(bytes, d, 32);
         int ok = 1;
         for (unsigned k = 0; k < D; k++) {
@@ -148,7 +148,7 @@ uint64_t or_coin_sizeof(void) { return sizeof(or_coin); }
 static uint64_t digest_head(int hasher, const uint8_t d[32]) {
     uint8_t bytes[32];
     uint64_t v;
-    if (hasher == 1) or_rp64_digest_as_bytes((const uint64_t *)d, bytes);
+    if (hasher == 1 || hasher == 3) or_rp64_digest_as_bytes((const uint64_t *)d, bytes);   /* both ElementDigest */
     else memcpy(bytes, d, 32);
     memcpy(&v, bytes, 8);
     return v;

@@ -148,3 +148,32 @@ def test_sha3_256_pinned_to_hashlib(oracle):
         hashlib.sha3_256(two[0].tobytes() + (0x0102030405060708).to_bytes(8, "little")).digest()
     many = np.arange(96, dtype=np.uint8).reshape(3, 32)
     assert oracle.merge_many(2, many).tobytes() == hashlib.sha3_256(many.tobytes()).digest()
+
+
+def test_rpjive64_permutation_kat_and_properties(oracle):
+    """crypto/src/hash/rescue/rp64_256_jive/tests.rs:69-97 (apply_permutation known answer from the sage reference
+    implementation) and the structural tests :99-178 (Jive merge differs from the sponge, padding)."""
+    import ctypes
+    lib = oracle.lib()
+    st = np.array([oracle.f64_new(i) for i in range(8)], dtype=np.uint64)
+    lib.or_rpjive_apply_permutation(st.ctypes.data_as(ctypes.c_void_p))
+    assert [int(oracle.f64_as_int(int(v))) for v in st] == [
+        16940713730596720799, 16218555904323712189, 11042680722444601138, 5370396747047489939,
+        6349480890410006944, 1551053614279730715, 3995941143622927528, 9350074312471431779]
+    H = 3
+    el = oracle.f64_from_int(np.arange(11, 19, dtype=np.uint64))
+    two = el.view(np.uint8).reshape(2, 32)
+    assert not np.array_equal(oracle.merge(H, two), oracle.hash_elements(H, el))                  # tests.rs:99-114
+    seed = two[0]
+    assert not np.array_equal(oracle.merge_with_int(H, seed, 77), oracle.hash_elements(H, np.append(el[:4], np.uint64(oracle.f64_new(77)))))
+    e2 = oracle.f64_from_int(np.array([5, 6], dtype=np.uint64))
+    assert not np.array_equal(oracle.hash_elements(H, e2), oracle.hash_elements(H, np.append(e2, np.uint64(0))))   # tests.rs:169-178
+    # merge = Jive: initial halves + permuted halves
+    st = el.copy()
+    lib.or_rpjive_apply_permutation(st.ctypes.data_as(ctypes.c_void_p))
+    P_ = 0xFFFFFFFF00000001
+    want = [(int(el[i]) + int(el[4 + i]) + int(st[i]) + int(st[4 + i])) % P_ for i in range(4)]   # Montgomery form is linear
+    assert [int(v) for v in oracle.merge(H, two).view(np.uint64)] == want
+    # merge_many = hash_elements over the digests' elements (mod.rs:219-221)
+    many = oracle.f64_from_int(np.arange(1, 13, dtype=np.uint64))
+    assert np.array_equal(oracle.merge_many(H, many.view(np.uint8).reshape(3, 32)), oracle.hash_elements(H, many))

@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, default_context, ptr
+from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, default_context, ptr
 from ..math import fields
 
 
@@ -90,3 +90,9 @@ class Rp64_256(_Hasher):
     def digest_as_bytes(digest):
         """ElementDigest::as_bytes — canonical little-endian (rp64_256/digest.rs:36-45)."""
         return fields.to_ints(np.ascontiguousarray(digest).view(np.uint64)).tobytes()
+
+
+class RpJive64_256(Rp64_256):
+    """crypto::hash::RpJive64_256 (crypto/src/hash/rescue/rp64_256_jive/mod.rs:62-313): ElementDigest as Rp64_256;
+    merge is the Jive compression, merge_many = hash_elements over the digests' elements (mod.rs:219-221)."""
+    HASH_ID = WF_HASH_RPJIVE64_256

@@ -14,6 +14,7 @@
 #include "keccak.cuh"
 #include "fields.cuh"
 #include "rp64.cuh"
+#include "rpjive64.cuh"
 #include "wf_internal.h"
 
 namespace {
@@ -58,6 +59,59 @@ struct HBlake3 {
         };
         if (MULTI) b3::hash_words(w, nelem * 2, out);
         else b3::chunk(w, 0, nelem * 2, 0, true, out);                           // <= 1024 bytes: a single chunk, no CV stack
+    }
+};
+
+// RpJive64_256 (crypto/src/hash/rescue/rp64_256_jive/mod.rs): ElementDigest like Rp64_256, width-8 permutation
+struct HRpJive {
+    static constexpr uint32_t STAGE_LEVELS = 1;      // as for Rp64_256: one full-width level per launch
+    static const char *row_name() { return "hash_rows_rpjive"; }
+    static const char *merkle_name() { return "merkle_stage_rpjive"; }
+    static const char *grind_name() { return "grind_rpjive"; }
+    static __device__ __forceinline__ void put(const uint64_t (&d)[4], uint32_t (&out)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
+        uint64_t two[8], d[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) two[i] = (uint64_t)in[2 * i] | ((uint64_t)in[2 * i + 1] << 32);
+        rpj::merge(two, d);
+        put(d, out);
+    }
+    // merge_with_int (mod.rs:223-263): seed in state[0..4], value in state[4] (and [5] when it exceeds the modulus),
+    // element count in state[7]; Jive summation with the initial state
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint64_t st[8], init[8], d[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) st[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) st[i] = (uint64_t)seed[2 * i] | ((uint64_t)seed[2 * i + 1] << 32);
+        constexpr uint64_t R2 = 0xfffffffe00000001ull;
+        st[4] = gl::mul(value >= gl::P ? value - gl::P : value, R2);
+        if (value < gl::P) st[7] = rp64::mont_small(5);
+        else {
+            st[5] = rp64::mont_small(1);
+            st[7] = rp64::mont_small(6);
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) init[i] = st[i];
+        rpj::permute(st);
+        rpj::jive_sum(init, st, d);
+        put(d, out);
+    }
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) {
+        return gl::to_int((uint64_t)d[0] | ((uint64_t)d[1] << 32));
+    }
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto e = [&](uint32_t i) -> uint64_t { return p[i]; };
+        rpj::hash_elements(e, nelem, d);
+        put(d, out);
     }
 };
 
@@ -351,7 +405,9 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
 }
 
 int check_hash(int hash) {
-    return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256 || hash == WF_HASH_SHA3_256) ? WF_OK : WF_ERR_UNSUPPORTED;
+    return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256 || hash == WF_HASH_SHA3_256 || hash == WF_HASH_RPJIVE64_256)
+               ? WF_OK
+               : WF_ERR_UNSUPPORTED;
 }
 
 // run fn(H{}) with the hasher policy selected by `hash`
@@ -361,6 +417,7 @@ int with_hasher(int hash, FN &&fn) {
         case WF_HASH_BLAKE3_256: return fn(HBlake3{});
         case WF_HASH_RP64_256: return fn(HRp64{});
         case WF_HASH_SHA3_256: return fn(HSha3{});
+        case WF_HASH_RPJIVE64_256: return fn(HRpJive{});
         default: return WF_ERR_UNSUPPORTED;
     }
 }
@@ -395,7 +452,7 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
     if (!ctx || !d_rows || !d_leaves || num_rows == 0 || D == 0) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
-    if (field != WF_FIELD_F64 && hash == WF_HASH_RP64_256) return WF_ERR_UNSUPPORTED;   // Rp64_256 is defined over f64 only
+    if (field != WF_FIELD_F64 && (hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256)) return WF_ERR_UNSUPPORTED;   // Rescue over f64 only
     if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
     if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
     // f64 is not IS_CANONICAL: hash the canonical LE bytes; f128 is: hash the raw element bytes (blake/mod.rs:52-65).
@@ -486,7 +543,7 @@ extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grin
     uint32_t lg = grinding_factor + 1;
     if (lg < 16) lg = 16;
     if (lg > 24) lg = 24;
-    if (hash == WF_HASH_RP64_256 && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
+    if ((hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256) && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
     if (hash == WF_HASH_SHA3_256 && lg > 23) lg = 23;
     const uint64_t batch = 1ull << lg;
     uint64_t first = first_nonce;

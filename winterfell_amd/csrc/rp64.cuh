@@ -35,44 +35,46 @@ __device__ __forceinline__ uint64_t exp7(uint64_t x) {
 
 // acc[i] = acc[i]^(2^N) * tail[i] for all 12 lanes of the state; the squaring runs are real loops (small code,
 // 12 independent multiplication chains in flight) — exp_acc of crypto/src/hash/rescue/mod.rs:20-28
-template <int N>
-__device__ __forceinline__ void exp_acc(uint64_t (&acc)[12], const uint64_t (&tail)[12]) {
+template <int N, int W>
+__device__ __forceinline__ void exp_acc(uint64_t (&acc)[W], const uint64_t (&tail)[W]) {
 #pragma unroll 1
     for (int k = 0; k < N; k++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) acc[i] = gl::sqr(acc[i]);
+        for (int i = 0; i < W; i++) acc[i] = gl::sqr(acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = gl::mul(acc[i], tail[i]);
+    for (int i = 0; i < W; i++) acc[i] = gl::mul(acc[i], tail[i]);
 }
 
 // x^(1/7) = x^10540996611094048183 with the 72-multiplication addition chain of rp64_256/mod.rs:351-384
-__device__ __forceinline__ void inv_sbox(uint64_t (&st)[12]) {
-    uint64_t t1[12], t2[12], t3[12], acc[12];
+// (the same chain in rp64_256_jive/mod.rs:393-426 for the width-8 state)
+template <int W>
+__device__ __forceinline__ void inv_sbox(uint64_t (&st)[W]) {
+    uint64_t t1[W], t2[W], t3[W], acc[W];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < W; i++) {
         t1[i] = gl::sqr(st[i]);   // x^10b
         t2[i] = gl::sqr(t1[i]);   // x^100b
         t3[i] = t2[i];
     }
-    exp_acc<3>(t3, t2);           // t3 = x^100100b
+    exp_acc<3, W>(t3, t2);        // t3 = x^100100b
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = t3[i];
-    exp_acc<6>(acc, t3);          // t4 = x^100100100100b
+    for (int i = 0; i < W; i++) acc[i] = t3[i];
+    exp_acc<6, W>(acc, t3);       // t4 = x^100100100100b
     {
-        uint64_t t4[12];
+        uint64_t t4[W];
 #pragma unroll
-        for (int i = 0; i < 12; i++) t4[i] = acc[i];
-        exp_acc<12>(acc, t4);     // t5
+        for (int i = 0; i < W; i++) t4[i] = acc[i];
+        exp_acc<12, W>(acc, t4);  // t5
     }
-    exp_acc<6>(acc, t3);          // t6
+    exp_acc<6, W>(acc, t3);       // t6
     {
-        uint64_t t6[12];
+        uint64_t t6[W];
 #pragma unroll
-        for (int i = 0; i < 12; i++) t6[i] = acc[i];
-        exp_acc<31>(acc, t6);     // t7
+        for (int i = 0; i < W; i++) t6[i] = acc[i];
+        exp_acc<31, W>(acc, t6);  // t7
 #pragma unroll
-        for (int i = 0; i < 12; i++) {
+        for (int i = 0; i < W; i++) {
             uint64_t a = gl::sqr(gl::sqr(gl::mul(gl::sqr(acc[i]), t6[i])));
             uint64_t b = gl::mul(gl::mul(t1[i], t2[i]), st[i]);
             st[i] = gl::mul(a, b);
@@ -162,7 +164,7 @@ __device__ __forceinline__ void permute(uint64_t (&st)[12]) {
         mds(st);
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], ARK1_T.v[r][i]);
-        inv_sbox(st);
+        inv_sbox<12>(st);
         mds(st);
 #pragma unroll
         for (int i = 0; i < 12; i++) st[i] = gl::add(st[i], ARK2_T.v[r][i]);
