@@ -55,7 +55,8 @@ enum {                                   /* crypto/src/hash/... */
     WF_HASH_BLAKE3_256 = 0,              /* blake/mod.rs:24-66                                  */
     WF_HASH_RP64_256 = 1,                /* rescue/rp64_256/mod.rs (f64 only)                   */
     WF_HASH_SHA3_256 = 2,                /* sha/mod.rs:21-66                                    */
-    WF_HASH_RPJIVE64_256 = 3             /* rescue/rp64_256_jive/mod.rs (f64 only, Jive 2-to-1) */
+    WF_HASH_RPJIVE64_256 = 3,            /* rescue/rp64_256_jive/mod.rs (f64 only, Jive 2-to-1) */
+    WF_HASH_RP62_248 = 4                 /* rescue/rp62_248/mod.rs (f62 only)                   */
 };
 
 /* ---- context / memory ------------------------------------------------------------------------------ */

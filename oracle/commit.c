@@ -45,7 +45,11 @@ void or_rpjive_hash_elements(const uint64_t *e, uint64_t n, uint64_t digest[4]);
 void or_rpjive_merge(const uint64_t two[8], uint64_t digest[4]);
 void or_rpjive_merge_with_int(const uint64_t seed[4], uint64_t value, uint64_t digest[4]);
 
-enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2, H_RPJIVE64 = 3 };
+void or_rp62_hash_elements(const uint64_t *e, uint64_t n, uint64_t digest[4]);
+void or_rp62_merge(const uint64_t two[8], uint64_t digest[4]);
+void or_rp62_merge_with_int(const uint64_t seed[4], uint64_t value, uint64_t digest[4]);
+
+enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2, H_RPJIVE64 = 3, H_RP62 = 4 /* f62 only: field_f62.c */ };
 
 /* the byte hash behind a ByteDigest hasher: Blake3_256 (blake/mod.rs) or Sha3_256 (sha/mod.rs) — the two hashers have
  * the same structure (hash of bytes / concatenated digests / seed || int / canonical element bytes) */
@@ -77,6 +81,7 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
 void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_merge((const uint64_t *)two, (uint64_t *)digest);
     else if (hasher == H_RPJIVE64) or_rpjive_merge((const uint64_t *)two, (uint64_t *)digest);
+    else if (hasher == H_RP62) or_rp62_merge((const uint64_t *)two, (uint64_t *)digest);                       /* rp62_248/mod.rs:156-166 */
     else or_bytes_hash(hasher, two, 64, digest);
 }
 
@@ -84,6 +89,7 @@ void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
 void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);
     else if (hasher == H_RPJIVE64) or_rpjive_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);  /* mod.rs:219-221 */
+    else if (hasher == H_RP62) or_rp62_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);        /* rp62_248/mod.rs:168-170 */
     else or_bytes_hash(hasher, digests, 32 * k, digest);
 }
 
@@ -93,6 +99,8 @@ void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, 
         or_rp64_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
     } else if (hasher == H_RPJIVE64) {
         or_rpjive_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
+    } else if (hasher == H_RP62) {
+        or_rp62_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
     } else {
         uint8_t data[40];
         memcpy(data, seed, 32);

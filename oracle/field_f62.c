@@ -30,7 +30,9 @@ static inline void f62_extD_mul(unsigned D, const uint64_t *a, const uint64_t *b
 }
 #define F_EXT_MUL f62_extD_mul
 /* Blake3_256<f62>::hash_elements: not IS_CANONICAL => canonical little-endian bytes of as_int() (blake/mod.rs:58-64) */
+void or_rp62_hash_elements(const uint64_t *e, uint64_t n, uint64_t digest[4]);
 static inline void f62_hash_elems(int hasher, const uint64_t *e, uint64_t n, uint8_t *digest) {
+    if (hasher == 4) { or_rp62_hash_elements(e, n, (uint64_t *)digest); return; }   /* Rp62_248 */
     uint64_t stackbuf[768];
     uint64_t *buf = n <= 768 ? stackbuf : (uint64_t *)malloc(n * 8);
     for (uint64_t i = 0; i < n; i++) buf[i] = f62_as_int(e[i]);

@@ -27,6 +27,7 @@ void or_f64_permute(uint64_t *v, uint64_t n, unsigned D);
 void or_f64_interpolate_poly_with_offset(uint64_t *ev, uint64_t n, unsigned D, const uint64_t *inv_twiddles,
                                          uint64_t domain_offset);
 void or_rp64_digest_as_bytes(const uint64_t digest[4], uint8_t out[32]);
+void or_rp62_digest_as_bytes(const uint64_t digest[4], uint8_t out[32]);
 
 /* transpose_slice::<E, N> — utils/core/src/lib.rs:166-183: result[i][j] = source[i + j * row_count] */
 void or_transpose_slice(const uint64_t *src, uint64_t len, unsigned D, uint64_t N, uint64_t *dst) {
@@ -149,6 +150,7 @@ static uint64_t digest_head(int hasher, const uint8_t d[32]) {
     uint8_t bytes[32];
     uint64_t v;
     if (hasher == 1 || hasher == 3) or_rp64_digest_as_bytes((const uint64_t *)d, bytes);   /* both ElementDigest */
+    else if (hasher == 4) or_rp62_digest_as_bytes((const uint64_t *)d, bytes);
     else memcpy(bytes, d, 32);
     memcpy(&v, bytes, 8);
     return v;

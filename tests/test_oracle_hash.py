@@ -177,3 +177,33 @@ def test_rpjive64_permutation_kat_and_properties(oracle):
     # merge_many = hash_elements over the digests' elements (mod.rs:219-221)
     many = oracle.f64_from_int(np.arange(1, 13, dtype=np.uint64))
     assert np.array_equal(oracle.merge_many(H, many.view(np.uint8).reshape(3, 32)), oracle.hash_elements(H, many))
+
+
+def test_rp62_248_permutation_kat_and_properties(oracle):
+    """crypto/src/hash/rescue/rp62_248/tests.rs:34-70 (apply_permutation known answer) and :72-125 (hash_elements of 8
+    elements == merge of the two digests, merge == merge_many, merge_with_int == hash_elements of seed + value)."""
+    import ctypes
+    lib = oracle.lib()
+    st = np.array([oracle.f62_new(i) for i in range(12)], dtype=np.uint64)
+    lib.or_rp62_apply_permutation(st.ctypes.data_as(ctypes.c_void_p))
+    assert [int(oracle.f62_as_int(int(v))) for v in st] == [
+        2176593392043442589, 3663362000910009411, 2446978550600442325, 4214718471639678996, 4179776369445579812,
+        2274316532403536457, 2336761070419368662, 3192888412646553651, 4092565229845701133, 753437048204208885,
+        4067414342325289862, 3516613610105678931]
+    H, f = 4, oracle.f62
+    el = np.array([oracle.f62_new(100 + i) for i in range(8)], dtype=np.uint64)
+    two = el.view(np.uint8).reshape(2, 32)
+    h8 = np.empty(32, dtype=np.uint8)
+    lib.or_rp62_hash_elements(el.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(8), h8.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(oracle.merge(H, two), h8)                                               # tests.rs:72-84
+    assert np.array_equal(oracle.merge_many(H, two), h8)                                          # tests.rs:86-98
+    seed = two[0]
+    e5 = np.append(el[:4], np.uint64(oracle.f62_new(12345)))
+    h5 = np.empty(32, dtype=np.uint8)
+    lib.or_rp62_hash_elements(e5.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(5), h5.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(oracle.merge_with_int(H, seed, 12345), h5)                              # tests.rs:100-112
+    big = oracle.F62_M + 2
+    e6 = np.append(el[:4], [np.uint64(oracle.f62_new(big)), np.uint64(oracle.f62_new(1))])
+    h6 = np.empty(32, dtype=np.uint8)
+    lib.or_rp62_hash_elements(e6.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(6), h6.ctypes.data_as(ctypes.c_void_p))
+    assert np.array_equal(oracle.merge_with_int(H, seed, big), h6)                                # tests.rs:114-124

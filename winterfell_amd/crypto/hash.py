@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, default_context, ptr
+from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, WF_HASH_RP62_248, default_context, ptr
 from ..math import fields
 
 
@@ -96,3 +96,27 @@ class RpJive64_256(Rp64_256):
     """crypto::hash::RpJive64_256 (crypto/src/hash/rescue/rp64_256_jive/mod.rs:62-313): ElementDigest as Rp64_256;
     merge is the Jive compression, merge_many = hash_elements over the digests' elements (mod.rs:219-221)."""
     HASH_ID = WF_HASH_RPJIVE64_256
+
+
+class Rp62_248(_Hasher):
+    """crypto::hash::Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs:62-239): Rescue-Prime over f62; a digest is four
+    f62 words (ElementDigest, digest.rs:16), serialised as 31 bytes."""
+    HASH_ID = WF_HASH_RP62_248
+
+    @classmethod
+    def hash_elements(cls, elements, ctx=None, field=fields.f62):
+        return super().hash_elements(elements, ctx, field)
+
+    @classmethod
+    def merge_many(cls, values, ctx=None):
+        v = np.ascontiguousarray(values).view(np.uint64).reshape(-1)
+        return cls.hash_elements(v, ctx)
+
+    @staticmethod
+    def digest_as_bytes(digest):
+        """ElementDigest::as_bytes (rp62_248/digest.rs:37-51): 4 x 62 bits packed little-endian."""
+        f = fields.f62
+        v = [f.as_int(int(w) % f.M) for w in np.ascontiguousarray(digest).view(np.uint64).reshape(4)]
+        words = [(v[0] | (v[1] << 62)) & (2**64 - 1), ((v[1] >> 2) | (v[2] << 60)) & (2**64 - 1),
+                 ((v[2] >> 4) | (v[3] << 58)) & (2**64 - 1), v[3] >> 6]
+        return np.array(words, dtype=np.uint64).tobytes()

@@ -13,6 +13,7 @@
 #include "blake3.cuh"
 #include "keccak.cuh"
 #include "fields.cuh"
+#include "rp62.cuh"
 #include "rp64.cuh"
 #include "rpjive64.cuh"
 #include "wf_internal.h"
@@ -111,6 +112,59 @@ struct HRpJive {
         uint64_t d[4];
         auto e = [&](uint32_t i) -> uint64_t { return p[i]; };
         rpj::hash_elements(e, nelem, d);
+        put(d, out);
+    }
+};
+
+// Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs): four f62 words per digest, defined over f62 only
+struct HRp62 {
+    static constexpr uint32_t STAGE_LEVELS = 1;
+    static const char *row_name() { return "hash_rows_rp62"; }
+    static const char *merkle_name() { return "merkle_stage_rp62"; }
+    static const char *grind_name() { return "grind_rp62"; }
+    static __device__ __forceinline__ void put(const uint64_t (&d)[4], uint32_t (&out)[8]) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
+        uint64_t two[8], d[4];
+#pragma unroll
+        for (int i = 0; i < 8; i++) two[i] = (uint64_t)in[2 * i] | ((uint64_t)in[2 * i + 1] << 32);
+        rp62::merge(two, d);
+        put(d, out);
+    }
+    // merge_with_int (mod.rs:172-201)
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint64_t st[12], d[4];
+#pragma unroll
+        for (int i = 0; i < 12; i++) st[i] = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) st[i] = f62::norm((uint64_t)seed[2 * i] | ((uint64_t)seed[2 * i + 1] << 32));
+        st[4] = rp62::to_mont(value % f62::M);
+        if (value < f62::M) st[11] = rp62::to_mont(5);
+        else {
+            st[5] = rp62::to_mont(value / f62::M);
+            st[11] = rp62::to_mont(6);
+        }
+        rp62::permute(st);
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = st[i];
+        put(d, out);
+    }
+    // ElementDigest::as_bytes packs 4 x 62 bits (digest.rs:37-51): the first 8 bytes are v1 | (v2 << 62)
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) {
+        const uint64_t v1 = f62::mul(f62::norm((uint64_t)d[0] | ((uint64_t)d[1] << 32)), 1);
+        const uint64_t v2 = f62::mul(f62::norm((uint64_t)d[2] | ((uint64_t)d[3] << 32)), 1);
+        return v1 | (v2 << 62);
+    }
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        auto e = [&](uint32_t i) -> uint64_t { return p[i]; };
+        rp62::hash_elements(e, nelem, d);
         put(d, out);
     }
 };
@@ -405,9 +459,7 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
 }
 
 int check_hash(int hash) {
-    return (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_RP64_256 || hash == WF_HASH_SHA3_256 || hash == WF_HASH_RPJIVE64_256)
-               ? WF_OK
-               : WF_ERR_UNSUPPORTED;
+    return (hash >= WF_HASH_BLAKE3_256 && hash <= WF_HASH_RP62_248) ? WF_OK : WF_ERR_UNSUPPORTED;
 }
 
 // run fn(H{}) with the hasher policy selected by `hash`
@@ -418,6 +470,7 @@ int with_hasher(int hash, FN &&fn) {
         case WF_HASH_RP64_256: return fn(HRp64{});
         case WF_HASH_SHA3_256: return fn(HSha3{});
         case WF_HASH_RPJIVE64_256: return fn(HRpJive{});
+        case WF_HASH_RP62_248: return fn(HRp62{});
         default: return WF_ERR_UNSUPPORTED;
     }
 }
@@ -453,6 +506,7 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
     WF_TRY(check_hash(hash));
     if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
     if (field != WF_FIELD_F64 && (hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256)) return WF_ERR_UNSUPPORTED;   // Rescue over f64 only
+    if (field != WF_FIELD_F62 && hash == WF_HASH_RP62_248) return WF_ERR_UNSUPPORTED;                                       // Rescue over f62 only
     if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
     if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
     // f64 is not IS_CANONICAL: hash the canonical LE bytes; f128 is: hash the raw element bytes (blake/mod.rs:52-65).
@@ -517,7 +571,7 @@ extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h
     if (!ctx || !h_seed || !d_out) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (count == 0) return WF_OK;
-    if (first_value + count < first_value) return WF_ERR_INVALID_ARG;
+    if (count - 1 > ~0ull - first_value) return WF_ERR_INVALID_ARG;   // the range must not wrap past u64::MAX
     const uint64_t blocks = (count + 255) / 256;
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
     Seed seed;
@@ -543,7 +597,7 @@ extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grin
     uint32_t lg = grinding_factor + 1;
     if (lg < 16) lg = 16;
     if (lg > 24) lg = 24;
-    if ((hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256) && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
+    if ((hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256 || hash == WF_HASH_RP62_248) && lg > 21) lg = 21;   // a Rescue permutation is ~200x a BLAKE3 block
     if (hash == WF_HASH_SHA3_256 && lg > 23) lg = 23;
     const uint64_t batch = 1ull << lg;
     uint64_t first = first_nonce;
