@@ -56,7 +56,8 @@ enum {                                   /* crypto/src/hash/... */
     WF_HASH_RP64_256 = 1,                /* rescue/rp64_256/mod.rs (f64 only)                   */
     WF_HASH_SHA3_256 = 2,                /* sha/mod.rs:21-66                                    */
     WF_HASH_RPJIVE64_256 = 3,            /* rescue/rp64_256_jive/mod.rs (f64 only, Jive 2-to-1) */
-    WF_HASH_RP62_248 = 4                 /* rescue/rp62_248/mod.rs (f62 only)                   */
+    WF_HASH_RP62_248 = 4,                /* rescue/rp62_248/mod.rs (f62 only)                   */
+    WF_HASH_BLAKE3_192 = 5               /* blake/mod.rs:68-125: 24-byte digests in 32-byte slots, bytes 24..31 zero */
 };
 
 /* ---- context / memory ------------------------------------------------------------------------------ */

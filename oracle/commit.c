@@ -49,13 +49,14 @@ void or_rp62_hash_elements(const uint64_t *e, uint64_t n, uint64_t digest[4]);
 void or_rp62_merge(const uint64_t two[8], uint64_t digest[4]);
 void or_rp62_merge_with_int(const uint64_t seed[4], uint64_t value, uint64_t digest[4]);
 
-enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2, H_RPJIVE64 = 3, H_RP62 = 4 /* f62 only: field_f62.c */ };
+enum { H_BLAKE3_F64 = 0, H_RP64 = 1, H_SHA3_F64 = 2, H_RPJIVE64 = 3, H_RP62 = 4 /* f62 only: field_f62.c */, H_BLAKE3_192 = 5 };
 
 /* the byte hash behind a ByteDigest hasher: Blake3_256 (blake/mod.rs) or Sha3_256 (sha/mod.rs) — the two hashers have
  * the same structure (hash of bytes / concatenated digests / seed || int / canonical element bytes) */
 void or_bytes_hash(int hasher, const uint8_t *in, uint64_t len, uint8_t out[32]) {
     if (hasher == H_SHA3_F64) or_sha3_256(in, len, out);
     else or_blake3_hash(in, len, out);
+    if (hasher == H_BLAKE3_192) memset(out + 24, 0, 8);   /* Blake3_192: result.as_bytes()[..24] (blake/mod.rs:81-84); slot tail zero */
 }
 
 /* ---------------------------------------------------------------------------------------------- */
@@ -82,7 +83,12 @@ void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]) {
     if (hasher == H_RP64) or_rp64_merge((const uint64_t *)two, (uint64_t *)digest);
     else if (hasher == H_RPJIVE64) or_rpjive_merge((const uint64_t *)two, (uint64_t *)digest);
     else if (hasher == H_RP62) or_rp62_merge((const uint64_t *)two, (uint64_t *)digest);                       /* rp62_248/mod.rs:156-166 */
-    else or_bytes_hash(hasher, two, 64, digest);
+    else if (hasher == H_BLAKE3_192) {                     /* digests_as_bytes of two ByteDigest<24>: 48 bytes (blake/mod.rs:86-88) */
+        uint8_t b[48];
+        memcpy(b, two, 24);
+        memcpy(b + 24, two + 32, 24);
+        or_bytes_hash(hasher, b, 48, digest);
+    } else or_bytes_hash(hasher, two, 64, digest);
 }
 
 /* merge_many — blake/mod.rs:37-39 (hash of concatenated bytes), rp64_256/mod.rs:194-196 */
@@ -90,7 +96,12 @@ void or_hash_merge_many(int hasher, const uint8_t *digests, uint64_t k, uint8_t 
     if (hasher == H_RP64) or_rp64_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);
     else if (hasher == H_RPJIVE64) or_rpjive_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);  /* mod.rs:219-221 */
     else if (hasher == H_RP62) or_rp62_hash_elements((const uint64_t *)digests, 4 * k, (uint64_t *)digest);        /* rp62_248/mod.rs:168-170 */
-    else or_bytes_hash(hasher, digests, 32 * k, digest);
+    else if (hasher == H_BLAKE3_192) {                     /* blake/mod.rs:90-92 */
+        uint8_t *b = (uint8_t *)malloc(24 * k);
+        for (uint64_t i = 0; i < k; i++) memcpy(b + 24 * i, digests + 32 * i, 24);
+        or_bytes_hash(hasher, b, 24 * k, digest);
+        free(b);
+    } else or_bytes_hash(hasher, digests, 32 * k, digest);
 }
 
 /* merge_with_int — blake/mod.rs:41-46, rp64_256/mod.rs:198-219 */
@@ -103,6 +114,12 @@ void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, 
         or_rp62_merge_with_int((const uint64_t *)seed, value, (uint64_t *)digest);
     } else {
         uint8_t data[40];
+        if (hasher == H_BLAKE3_192) {                      /* blake/mod.rs:94-103: [0; 32], seed in ..24, value in 24.. */
+            memcpy(data, seed, 24);
+            memcpy(data + 24, &value, 8);
+            or_bytes_hash(hasher, data, 32, digest);
+            return;
+        }
         memcpy(data, seed, 32);
         memcpy(data + 32, &value, 8);
         or_bytes_hash(hasher, data, 40, digest);

@@ -207,3 +207,27 @@ def test_rp62_248_permutation_kat_and_properties(oracle):
     h6 = np.empty(32, dtype=np.uint8)
     lib.or_rp62_hash_elements(e6.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(6), h6.ctypes.data_as(ctypes.c_void_p))
     assert np.array_equal(oracle.merge_with_int(H, seed, big), h6)                                # tests.rs:114-124
+
+
+def test_blake3_192_is_truncated_blake3(oracle):
+    """crypto/src/hash/blake/mod.rs:68-125: every Blake3_192 entry point is BLAKE3 of the reference's byte string,
+    truncated to 24 bytes (digests occupy 32-byte slots with a zero tail in the oracle and in the library)."""
+    import ctypes
+    lib = oracle.lib()
+
+    def b3(b):
+        out = np.empty(32, dtype=np.uint8)
+        a = np.frombuffer(b, dtype=np.uint8).copy()
+        lib.or_blake3_hash(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_uint64(len(b)), out.ctypes.data_as(ctypes.c_void_p))
+        return out.tobytes()
+
+    H = 5
+    ints = np.arange(3, 30, dtype=np.uint64)
+    d = oracle.hash_elements(H, oracle.f64_from_int(ints))
+    assert d.tobytes() == b3(ints.tobytes())[:24] + bytes(8)
+    two = np.arange(64, dtype=np.uint8).reshape(2, 32)
+    assert oracle.merge(H, two).tobytes() == b3(two[0, :24].tobytes() + two[1, :24].tobytes())[:24] + bytes(8)
+    assert oracle.merge_with_int(H, two[0], 0x1122334455667788).tobytes() == \
+        b3(two[0, :24].tobytes() + (0x1122334455667788).to_bytes(8, "little"))[:24] + bytes(8)
+    many = np.arange(96, dtype=np.uint8).reshape(3, 32)
+    assert oracle.merge_many(H, many).tobytes() == b3(b"".join(many[i, :24].tobytes() for i in range(3)))[:24] + bytes(8)

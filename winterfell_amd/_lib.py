@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, "libwinterfell_hip.so")
 
 WF_FIELD_F64, WF_FIELD_F128, WF_FIELD_F62 = 0, 1, 2
 WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, WF_HASH_RP62_248 = 0, 1, 2, 3, 4
+WF_HASH_BLAKE3_192 = 5
 
 _u32, _u64, _int, _vp = ctypes.c_uint32, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p
 

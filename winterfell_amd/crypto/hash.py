@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, WF_HASH_RP62_248, default_context, ptr
+from .._lib import WF_FIELD_F64, WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, WF_HASH_RP62_248, WF_HASH_BLAKE3_192, default_context, ptr
 from ..math import fields
 
 
@@ -69,6 +69,17 @@ class _Hasher:
 class Blake3_256(_Hasher):
     """crypto::hash::Blake3_256<f64::BaseElement> (crypto/src/hash/blake/mod.rs:24-66)."""
     HASH_ID = WF_HASH_BLAKE3_256
+
+
+class Blake3_192(_Hasher):
+    """crypto::hash::Blake3_192<B> (crypto/src/hash/blake/mod.rs:68-125): ByteDigest<24>.  The library keeps digests in
+    32-byte slots; for this hasher bytes 24..31 of a slot are zero and `digest_as_bytes` returns the 24 meaningful ones."""
+    HASH_ID = WF_HASH_BLAKE3_192
+    COLLISION_RESISTANCE = 96
+
+    @classmethod
+    def digest_as_bytes(cls, digest):
+        return np.ascontiguousarray(digest).view(np.uint8).tobytes()[:24]
 
 
 class Sha3_256(_Hasher):

@@ -20,7 +20,8 @@
 
 namespace {
 
-enum { MODE_F64_CANON = 0, MODE_RAW = 1, MODE_F62_CANON = 2 };
+// MODE_DIGESTS: the words are 32-byte digest slots (merge_many); identical to MODE_RAW except for 24-byte digests
+enum { MODE_F64_CANON = 0, MODE_RAW = 1, MODE_F62_CANON = 2, MODE_DIGESTS = 3 };
 
 struct Digest {
     uint32_t w[8];
@@ -60,6 +61,54 @@ struct HBlake3 {
         };
         if (MULTI) b3::hash_words(w, nelem * 2, out);
         else b3::chunk(w, 0, nelem * 2, 0, true, out);                           // <= 1024 bytes: a single chunk, no CV stack
+    }
+};
+
+// Blake3_192<B> (crypto/src/hash/blake/mod.rs:68-125): BLAKE3 truncated to 24 bytes.  Digests live in the library's
+// 32-byte slots with bytes 24..31 zero; what is hashed is the reference's byte string (48 bytes for a merge, 24 k bytes
+// for merge_many, seed[..24] || value for merge_with_int).
+struct HBlake3_192 {
+    static constexpr uint32_t STAGE_LEVELS = 10;
+    static const char *row_name() { return "hash_rows_blake3_192"; }
+    static const char *merkle_name() { return "merkle_stage_blake3_192"; }
+    static const char *grind_name() { return "grind_blake3_192"; }
+    static __device__ __forceinline__ void trunc(uint32_t (&out)[8]) { out[6] = out[7] = 0; }
+    static __device__ __forceinline__ void merge(const uint32_t (&in)[16], uint32_t (&out)[8]) {
+        uint32_t cv[8], m[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = b3::iv(i);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+            m[i] = in[i];
+            m[6 + i] = in[8 + i];
+        }
+        m[12] = m[13] = m[14] = m[15] = 0;
+        b3::compress(cv, m, 0, 48, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, out);
+        trunc(out);
+    }
+    static __device__ __forceinline__ void merge_with_int(const uint32_t (&seed)[8], uint64_t value, uint32_t (&out)[8]) {
+        uint32_t cv[8], m[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = b3::iv(i);
+#pragma unroll
+        for (int i = 0; i < 16; i++) m[i] = i < 6 ? seed[i] : 0;
+        m[6] = (uint32_t)value;
+        m[7] = (uint32_t)(value >> 32);
+        b3::compress(cv, m, 0, 32, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT, out);
+        trunc(out);
+    }
+    static __device__ __forceinline__ uint64_t head(const uint32_t (&d)[8]) { return (uint64_t)d[0] | ((uint64_t)d[1] << 32); }
+    template <int MODE, bool MULTI>
+    static __device__ __forceinline__ void hash_elems(const uint64_t *p, uint32_t nelem, uint32_t (&out)[8]) {
+        if (MODE == MODE_DIGESTS) {
+            // nelem / 4 digest slots, 6 message words each
+            const uint32_t *q = reinterpret_cast<const uint32_t *>(p);
+            auto w = [&](uint32_t i) -> uint32_t { return q[(i / 6) * 8 + (i % 6)]; };
+            b3::hash_words(w, (nelem / 4) * 6, out);
+        } else {
+            HBlake3::hash_elems<MODE, MULTI>(p, nelem, out);
+        }
+        trunc(out);
     }
 };
 
@@ -418,6 +467,7 @@ int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint6
     switch (mode) {
         case MODE_F64_CANON: WF_HR(MODE_F64_CANON);
         case MODE_F62_CANON: WF_HR(MODE_F62_CANON);
+        case MODE_DIGESTS: WF_HR(MODE_DIGESTS);
         default: WF_HR(MODE_RAW);
     }
 #undef WF_HR
@@ -459,7 +509,7 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
 }
 
 int check_hash(int hash) {
-    return (hash >= WF_HASH_BLAKE3_256 && hash <= WF_HASH_RP62_248) ? WF_OK : WF_ERR_UNSUPPORTED;
+    return (hash >= WF_HASH_BLAKE3_256 && hash <= WF_HASH_BLAKE3_192) ? WF_OK : WF_ERR_UNSUPPORTED;
 }
 
 // run fn(H{}) with the hasher policy selected by `hash`
@@ -471,6 +521,7 @@ int with_hasher(int hash, FN &&fn) {
         case WF_HASH_SHA3_256: return fn(HSha3{});
         case WF_HASH_RPJIVE64_256: return fn(HRpJive{});
         case WF_HASH_RP62_248: return fn(HRp62{});
+        case WF_HASH_BLAKE3_192: return fn(HBlake3_192{});
         default: return WF_ERR_UNSUPPORTED;
     }
 }
@@ -538,7 +589,7 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
     return with_hasher(hash, [&](auto h) {
         typedef decltype(h) H;
         WF_TRY(launch_hash_rows<H>(ctx, rows, num_rows, row_width, elems_per_row, ps * D, parts, mode, tmp));
-        return launch_hash_rows<H>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_RAW, d_leaves);
+        return launch_hash_rows<H>(ctx, (const uint64_t *)tmp, num_rows, 4ull * parts, 4 * parts, 4 * parts, 1, MODE_DIGESTS, d_leaves);
     });
 }
 
@@ -562,7 +613,7 @@ extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_dig
     // Blake3: hash of the concatenated digest bytes (blake/mod.rs:37-39); Rp64_256: hash_elements over the 4*k digest
     // elements (rp64_256/mod.rs:194-196).  Both are "raw words" for the row kernel.
     return with_hasher(hash, [&](auto h) {
-        return launch_hash_rows<decltype(h)>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_RAW, d_out);
+        return launch_hash_rows<decltype(h)>(ctx, (const uint64_t *)d_digests, count, 4ull * k, 4 * k, 4 * k, 1, MODE_DIGESTS, d_out);
     });
 }
 
