@@ -1,0 +1,248 @@
+"""End-to-end composition of the device pieces in the order of Prover::generate_proof (prover/src/lib.rs:275-470) for the two
+example AIRs, driven by a host Fiat-Shamir coin, followed by an independent re-check of what a verifier would check from
+the queried data (verifier/src/lib.rs:139-330): Merkle openings, the out-of-domain constraint equation, DEEP composition at
+every query position, and the FRI fold chain down to the remainder.  The coin below is a python restatement of
+DefaultRandomCoin (crypto/src/random/default.rs) on the library's hashers; the exact transcript serialisation of the
+reference's ProverChannel (context / proof bytes) is out of scope, so this is a consistency test of the pipeline, not a
+byte-level proof comparison."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+class Coin:
+    """DefaultRandomCoin: seed = hash_elements(seed elements); reseed = merge(seed, data); next = merge_with_int(seed, ++counter)."""
+
+    def __init__(self, hasher, fld, seed_words):
+        self.h, self.f = hasher, fld
+        self.seed = hasher.hash_elements(np.asarray(seed_words, dtype=np.uint64), field=fld)
+        self.counter = 0
+
+    def reseed(self, digest):
+        self.seed = self.h.merge(np.stack([self.seed, np.asarray(digest, dtype=np.uint8).reshape(32)]))
+        self.counter = 0
+
+    def _next(self):
+        self.counter += 1
+        return self.h.digest_as_bytes(self.h.merge_with_int(self.seed, self.counter))
+
+    def draw(self, D):
+        """draw::<E>: the first ELEMENT_BYTES of next() must decode to canonical base elements (default.rs:185-199)."""
+        f = self.f
+        nb = 8 * f.W
+        for _ in range(1000):
+            b = self._next()
+            vals = [int.from_bytes(b[k * nb:(k + 1) * nb], "little") for k in range(D)]
+            if len(b) >= D * nb and all(v < f.M for v in vals):
+                return f.pack([f.new(v) for v in vals])
+        raise RuntimeError("failed to draw")
+
+    def draw_integers(self, num, domain_size, nonce):
+        self.seed = self.h.merge_with_int(self.seed, nonce)
+        self.counter = 0
+        return [int.from_bytes(self._next()[:8], "little") & (domain_size - 1) for _ in range(num)]
+
+
+class FriChannel:
+    def __init__(self, coin, D):
+        self.coin, self.D, self.commitments, self.alphas = coin, D, [], []
+
+    def commit_fri_layer(self, root):
+        self.commitments.append(np.array(root, copy=True))
+        self.coin.reseed(root)
+
+    def draw_fri_alpha(self):
+        a = self.coin.draw(self.D)
+        self.alphas.append(a)
+        return a
+
+
+class ExtOps:
+    """degree-D extension arithmetic on internal-form python ints through the oracle's scalar field functions"""
+
+    def __init__(self, ofld, D, one):
+        self.o, self.D, self.one = ofld, D, one
+
+    def add(self, a, b): return [self.o.add(x, y) for x, y in zip(a, b)]
+    def sub(self, a, b): return [self.o.sub(x, y) for x, y in zip(a, b)]
+    def mul(self, a, b): return self.o.ext_mul(self.D, a, b)
+    def lift(self, v): return [v] + [0] * (self.D - 1)
+
+    def pow(self, a, e):
+        r = self.lift(self.one)
+        while e:
+            if e & 1:
+                r = self.mul(r, a)
+            a = self.mul(a, a)
+            e >>= 1
+        return r
+
+
+@pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 2), ("fib_small", "f64", "Rp64_256", 1 << 8, 1),
+                                                      ("rescue", "f128", "Blake3_256", 1 << 9, 2), ("rescue", "f128", "Sha3_256", 1 << 8, 1)])
+def test_prove_then_check(oracle, example, fname, hname, n, D):
+    import winterfell_amd
+    from winterfell_amd import air as wair, crypto, fri, prover
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    hasher = getattr(crypto, hname)
+    fld, ofld = {"f64": (fields.f64, oracle.f64t), "f128": (fields.f128, oracle.f128)}[fname]
+    blowup, folding, rem_deg, num_queries, grinding = 8, 4, 7, 12, 8
+    W, ew = fld.W, D * fld.W
+    one = fld.new(1)
+    E = ExtOps(ofld, D, one)
+    # ---- 1. trace, AIR, public inputs -> coin seed (prover/src/lib.rs:284-297)
+    if example == "fib_small":
+        trace = ofld.fib_small_build_trace(n)
+        result = fld.unpack(trace[1])[n - 1]
+        air = wair.FibSmall(n, result, blowup, fld)
+        pub = [result]
+        air_id = 0
+    else:
+        trace = ofld.rescue_build_trace([42, 43], n // 16)
+        t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
+        air = wair.RescueAir(n, [t0[0], t1[0]], [t0[n - 1], t1[n - 1]], blowup)
+        pub = [t0[0], t1[0], t0[n - 1], t1[n - 1]]
+        air_id = 1
+    coin = Coin(hasher, fld, fld.pack(pub))
+    domain = prover.StarkDomain(n, blowup, field=fld)
+    N = n * blowup
+    # ---- 2. commit to the main trace (lib.rs:305-306)
+    trace_lde, trace_polys = prover.DefaultTraceLde.new(hasher, prover.ColMatrix(trace, 1, ctx, fld), domain)
+    coin.reseed(trace_lde.get_main_trace_commitment())
+    # ---- 3. constraint composition coefficients, evaluation, commitment (lib.rs:353-371)
+    nt, na = air.num_transition_constraints(), air.num_assertions()
+    cc = prover.ConstraintCompositionCoefficients(np.stack([coin.draw(D) for _ in range(nt)]), np.stack([coin.draw(D) for _ in range(na)]))
+    evaluator = prover.DefaultConstraintEvaluator(air, cc, D)
+    comp_trace = evaluator.evaluate(trace_lde, domain)
+    ncols = air.num_constraint_composition_columns()
+    constraint_com, comp_poly = prover.build_constraint_commitment(hasher, comp_trace, ncols, domain, ext_degree=D, field=fld, ctx=ctx)
+    coin.reseed(constraint_com.commitment())
+    # ---- 4. OOD point, frames, DEEP composition (lib.rs:373-421)
+    z = coin.draw(D)
+    table = prover.TracePolyTable(trace_polys)
+    ood_cur, ood_next = table.get_ood_frame(z, D)
+    q_cur, q_next = prover.composition_poly_ood_frame(comp_poly, z, D)
+    coin.reseed(hasher.hash_elements(np.concatenate([ood_cur.reshape(-1), ood_next.reshape(-1), q_cur.reshape(-1), q_next.reshape(-1)]), field=fld))
+    width = air.TRACE_WIDTH
+    cc_t, cc_c = np.stack([coin.draw(D) for _ in range(width)]), np.stack([coin.draw(D) for _ in range(ncols)])
+    deep = prover.DeepCompositionPoly(z, cc_t, cc_c, D)
+    deep.add_trace_polys(table, comp_poly, (ood_cur, ood_next), (q_cur, q_next))
+    assert deep.degree() == n - 2                                               # lib.rs:423
+    deep_ev = deep.evaluate(domain)
+    # ---- 5. FRI commit phase (lib.rs:433-440)
+    fopts = fri.FriOptions(blowup, folding, rem_deg, field=fld)
+    fchan = FriChannel(coin, D)
+    fprover = fri.FriProver(fopts, hasher, ext_degree=D)
+    fprover.build_layers(fchan, deep_ev)
+    # ---- 6. grinding + query positions (lib.rs:444-459)
+    nonce = crypto.grind_query_seed(hasher, coin.seed, grinding)
+    assert crypto.check_leading_zeros(hasher, coin.seed, nonce) >= grinding
+    positions = sorted(set(coin.draw_integers(num_queries, N, nonce)))
+    (t_rows, (t_leaves, t_proof)), = trace_lde.query(positions)
+    c_rows, (c_leaves, c_proof) = constraint_com.query(positions)
+
+    # ================= the checks a verifier would make =================
+    # (a) Merkle openings of the queried rows against the two commitments
+    assert crypto.MerkleTree.verify_batch(hasher, trace_lde.get_main_trace_commitment(), positions, t_leaves, t_proof) is None
+    assert crypto.MerkleTree.verify_batch(hasher, constraint_com.commitment(), positions, c_leaves, c_proof) is None
+    lv = hasher.hash_elements(np.ascontiguousarray(t_rows), field=fld)
+    assert all(np.array_equal(lv[k], t_leaves[k]) for k in range(len(positions)))
+    # (b) the OOD constraint equation (verifier/src/evaluator.rs:16-89 vs sum_i z^(i n) H_i(z))
+    zi = fld.unpack(z)
+    g = fld.new(fld.get_root_of_unity(n.bit_length() - 1))
+    zn = E.pow(zi, n)
+    H, zp = [0] * D, E.lift(one)
+    for i in range(ncols):
+        H = E.add(H, E.mul(zp, fld.unpack(q_cur[i])))
+        zp = E.mul(zp, zn)
+    per = np.zeros(0, dtype=np.uint64)
+    if air_id == 1:
+        per = ofld.evaluate_columns_at(ofld.air_periodic_polys(1), 9, fld.pack(E.pow(zi, n // 16)), D, 1).reshape(-1)
+    tev = fld.unpack(ofld.air_evaluate_transition(air_id, D, ood_cur.reshape(-1), ood_next.reshape(-1), per))
+    T = [0] * D
+    for k in range(nt):
+        T = E.add(T, E.mul(fld.unpack(cc.transition[k]), tev[k * D:(k + 1) * D]))
+    num_t, den_t = E.sub(zn, E.lift(one)), E.sub(zi, E.lift(ofld.exp(g, n - 1)))
+    groups, curl = {}, fld.unpack(ood_cur.reshape(-1))
+    for a, ccb in zip(evaluator.assertions, cc.boundary):
+        ev = E.sub(curl[a.column * D:(a.column + 1) * D], E.lift(a.value))
+        groups[a.first_step] = E.add(groups.get(a.first_step, [0] * D), E.mul(fld.unpack(ccb), ev))
+    divs = {s: E.sub(zi, E.lift(ofld.exp(g, s))) for s in groups}
+    prod_all = E.lift(one)
+    for d in divs.values():
+        prod_all = E.mul(prod_all, d)
+    rhs = E.mul(E.mul(T, den_t), prod_all)
+    for s, B in groups.items():
+        other = E.lift(one)
+        for s2, d in divs.items():
+            if s2 != s:
+                other = E.mul(other, d)
+        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
+    assert E.mul(E.mul(H, num_t), prod_all) == rhs
+    # (c) DEEP composition at every query position from the opened rows (verifier/src/composer.rs)
+    g_lde = fld.new(fld.get_root_of_unity(N.bit_length() - 1))
+    zg = E.mul(zi, E.lift(g))
+    layer0 = ctx.to_host(fprover.layers[0].evaluations)                          # [rc][folding * ew]
+    rc0 = N // folding
+    for k, p in enumerate(positions):
+        x = E.lift(ofld.mul(int(domain.offset), ofld.exp(g_lde, p)))
+        dz, dzg = E.sub(x, zi), E.sub(x, zg)
+        acc = [0] * D
+        trow = fld.unpack(t_rows[k])
+        for i in range(width):
+            tx = E.lift(trow[i])
+            term = E.add(E.mul(E.sub(tx, fld.unpack(ood_cur[i])), dzg), E.mul(E.sub(tx, fld.unpack(ood_next[i])), dz))
+            acc = E.add(acc, E.mul(fld.unpack(cc_t[i]), term))
+        crow = fld.unpack(c_rows[k])
+        for i in range(ncols):
+            hx = crow[i * D:(i + 1) * D]
+            term = E.add(E.mul(E.sub(hx, fld.unpack(q_cur[i])), dzg), E.mul(E.sub(hx, fld.unpack(q_next[i])), dz))
+            acc = E.add(acc, E.mul(fld.unpack(cc_c[i]), term))
+        got = fld.unpack(layer0[p % rc0][(p // rc0) * ew:(p // rc0 + 1) * ew])
+        assert E.mul(E.mul(got, dz), dzg) == acc, p
+    # (d) FRI: layer commitments open, each queried row folds into the next layer, the last one into the remainder
+    pos = positions
+    length = N
+    for li, layer in enumerate(fprover.layers):
+        rc = length // folding
+        rows_idx = sorted(set(p % rc for p in pos))
+        leaves, proof = layer.commitment.prove_batch(rows_idx)
+        assert crypto.MerkleTree.verify_batch(hasher, fchan.commitments[li], rows_idx, leaves, proof) is None
+        rows = ctx.to_host(layer.evaluations)
+        nxt_rows = ctx.to_host(fprover.layers[li + 1].evaluations) if li + 1 < len(fprover.layers) else None
+        for r in rows_idx:
+            if fname == "f64":
+                folded = oracle.apply_drp_rows(rows[r], folding, length, r, int(fopts.domain_offset()), fchan.alphas[li], D)
+            else:
+                # generic-field oracle folds whole layers only: fold the layer once and pick the row
+                folded = None
+            if folded is not None:
+                if nxt_rows is not None:
+                    rc2 = rc // folding
+                    assert np.array_equal(folded, nxt_rows[r % rc2][(r // rc2) * ew:(r // rc2 + 1) * ew])
+                else:
+                    # remainder polynomial (reversed coefficients, prover/mod.rs:230-239) at offset * g_rc^r
+                    gl_ = fld.new(fld.get_root_of_unity(rc.bit_length() - 1))
+                    x = E.lift(ofld.mul(int(fopts.domain_offset()), ofld.exp(gl_, r)))
+                    acc = [0] * D
+                    for coef in fprover.remainder_poly.reshape(-1, ew):       # highest degree first
+                        acc = E.add(E.mul(acc, x), fld.unpack(coef))
+                    assert acc == fld.unpack(folded)
+        if fname != "f64":
+            full = ofld.apply_drp(rows.reshape(-1), folding, int(fopts.domain_offset()), fchan.alphas[li], D).reshape(rc, ew)
+            if nxt_rows is not None:
+                rc2 = rc // folding
+                for r in rows_idx:
+                    assert np.array_equal(full[r], nxt_rows[r % rc2][(r // rc2) * ew:(r // rc2 + 1) * ew])
+            else:
+                gl_ = fld.new(fld.get_root_of_unity(rc.bit_length() - 1))
+                for r in rows_idx:
+                    x = E.lift(ofld.mul(int(fopts.domain_offset()), ofld.exp(gl_, r)))
+                    acc = [0] * D
+                    for coef in fprover.remainder_poly.reshape(-1, ew):
+                        acc = E.add(E.mul(acc, x), fld.unpack(coef))
+                    assert acc == fld.unpack(full[r])
+        pos, length = rows_idx, rc
+    assert len(fchan.commitments) == fprover.num_layers() + 1
