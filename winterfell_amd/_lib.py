@@ -7,7 +7,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libwinterfell_hip.so")
+LIB_PATH = os.environ.get("WF_HIP_LIBRARY", os.path.join(_HERE, "libwinterfell_hip.so"))   # override: A/B-testing kernel variants
 
 WF_FIELD_F64, WF_FIELD_F128, WF_FIELD_F62 = 0, 1, 2
 WF_HASH_BLAKE3_256, WF_HASH_RP64_256, WF_HASH_SHA3_256, WF_HASH_RPJIVE64_256, WF_HASH_RP62_248 = 0, 1, 2, 3, 4

@@ -381,8 +381,9 @@ struct Deep {
                            const void *h_points, uint32_t num_points, void *h_out) {
         // segments: enough workgroups to fill the chip, at least 256 coefficients each
         const uint32_t log_thr = log_n < 8 ? log_n : 8;
+        // (the recombination kernel walks a column's segments sequentially: at most 64 of them)
         uint32_t log_seg = log_n;
-        while (log_seg > 12 && ((uint64_t)num_cols << (log_n - log_seg)) < 2048) log_seg--;
+        while (log_seg > 12 && log_n - log_seg < 6 && ((uint64_t)num_cols << (log_n - log_seg)) < 2048) log_seg--;
         if (log_seg < log_thr) log_seg = log_thr;
         const uint32_t nseg = 1u << (log_n - log_seg);
         void *tmp;

@@ -13,6 +13,7 @@ struct F64 {
     typedef uint64_t T;
     static constexpr int ID = WF_FIELD_F64;
     static constexpr int MAX_EXT = 3;
+    static constexpr uint32_t MAX_LOG_RADIX = 8;
     static constexpr bool SHIFT_TWIDDLES = true;
     static __device__ __forceinline__ T add(T a, T b) { return gl::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return gl::sub(a, b); }
@@ -40,6 +41,10 @@ struct F128 {
     typedef f128::u128 T;
     static constexpr int ID = WF_FIELD_F128;
     static constexpr int MAX_EXT = 2;   // no cubic extension (math/src/field/f128/mod.rs:288-308)
+#ifndef NTT_F128_MAX_LOG_RADIX
+#define NTT_F128_MAX_LOG_RADIX 6
+#endif
+    static constexpr uint32_t MAX_LOG_RADIX = NTT_F128_MAX_LOG_RADIX;
     static constexpr bool SHIFT_TWIDDLES = false;
     static __device__ __forceinline__ T add(T a, T b) { return f128::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return f128::sub(a, b); }
@@ -82,6 +87,7 @@ struct F62 {
     typedef uint64_t T;
     static constexpr int ID = WF_FIELD_F62;
     static constexpr int MAX_EXT = 3;
+    static constexpr uint32_t MAX_LOG_RADIX = 8;
     static constexpr bool SHIFT_TWIDDLES = false;
     static __device__ __forceinline__ T add(T a, T b) { return f62::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return f62::sub(a, b); }

@@ -37,7 +37,7 @@ struct PassParams {
     uint32_t log_n;
     uint32_t npass;
     uint32_t pass;
-    uint32_t log_r[4];
+    uint32_t log_r[6];
     uint32_t nvec;
     uint32_t src_div, src_inner, dst_inner;
     uint64_t src_vec_stride, dst_vec_stride;
@@ -219,9 +219,11 @@ inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
 
 }  // namespace
 
-// Split L bits into passes of at most 8 bits, as evenly as possible (largest first).
-static inline void plan_passes(uint32_t L, uint32_t &npass, uint32_t log_r[4]) {
-    npass = (L + 7) / 8;
+// Split L bits into passes of at most max_bits bits, as evenly as possible (largest first).  max_bits is 8 for the
+// 64-bit fields; f128 uses 6: a radix-256 pass of 16-byte elements needs 207 VGPRs and 70 KB of LDS per workgroup
+// (2 waves per SIMD), a radix-64 pass 116 VGPRs and 35 KB (4 waves per SIMD), which more than pays for the extra pass.
+static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, uint32_t log_r[6]) {
+    npass = (L + max_bits - 1) / max_bits;
     if (npass == 0) npass = 1;
     uint32_t rem = L;
     for (uint32_t q = 0; q < npass; q++) {
@@ -230,7 +232,7 @@ static inline void plan_passes(uint32_t L, uint32_t &npass, uint32_t log_r[4]) {
         log_r[q] = r;
         rem -= r;
     }
-    for (uint32_t q = npass; q < 4; q++) log_r[q] = 0;
+    for (uint32_t q = npass; q < 6; q++) log_r[q] = 0;
 }
 
 template <class HF>
@@ -242,7 +244,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     if (L > HF::TWO_ADICITY || L > 32) return WF_ERR_DOMAIN_TOO_LARGE;
     PassParams<T> p{};
     p.log_n = L;
-    plan_passes(L, p.npass, p.log_r);
+    plan_passes(L, F::MAX_LOG_RADIX, p.npass, p.log_r);
     p.nvec = job.nvec;
     p.inverse = job.inverse ? 1 : 0;
     SeriesTable om;
