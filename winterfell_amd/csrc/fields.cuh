@@ -13,7 +13,10 @@ struct F64 {
     typedef uint64_t T;
     static constexpr int ID = WF_FIELD_F64;
     static constexpr int MAX_EXT = 3;
-    static constexpr uint32_t MAX_LOG_RADIX = 8;
+#ifndef NTT_F64_MAX_LOG_RADIX
+#define NTT_F64_MAX_LOG_RADIX 8
+#endif
+    static constexpr uint32_t MAX_LOG_RADIX = NTT_F64_MAX_LOG_RADIX;
     static constexpr bool SHIFT_TWIDDLES = true;
     static __device__ __forceinline__ T add(T a, T b) { return gl::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return gl::sub(a, b); }
