@@ -32,6 +32,24 @@ __device__ __forceinline__ uint64_t mul_v2(uint64_t a, uint64_t b) {
     return gl::mont_red(lo, hi);
 }
 
+// row-wise 64 x 64 product: (l0, l1, h1) = a0 * b, (m0, m1, k1) = a1 * b, summed with one carry chain
+__device__ __forceinline__ uint64_t mul_v3(uint64_t a, uint64_t b) {
+    const uint32_t a0 = (uint32_t)a, a1 = (uint32_t)(a >> 32), b0 = (uint32_t)b, b1 = (uint32_t)(b >> 32);
+    uint64_t t = (uint64_t)a0 * b0;
+    const uint32_t l0 = (uint32_t)t;
+    t = (uint64_t)a0 * b1 + (t >> 32);
+    const uint32_t l1 = (uint32_t)t, h1 = (uint32_t)(t >> 32);
+    t = (uint64_t)a1 * b0;
+    const uint32_t m0 = (uint32_t)t;
+    t = (uint64_t)a1 * b1 + (t >> 32);
+    const uint32_t m1 = (uint32_t)t, k1 = (uint32_t)(t >> 32);
+    uint32_t c;
+    const uint32_t p1 = __builtin_addc(l1, m0, 0u, &c);
+    const uint32_t p2 = __builtin_addc(h1, m1, c, &c);
+    const uint32_t p3 = __builtin_addc(k1, 0u, c, &c);
+    return gl::mont_red(gl::join(l0, p1), gl::join(p2, p3));
+}
+
 template <int OP>
 __global__ __launch_bounds__(256) void k(uint64_t *out, uint64_t seed) {
     uint64_t x[CH], y[CH];
@@ -52,6 +70,7 @@ __global__ __launch_bounds__(256) void k(uint64_t *out, uint64_t seed) {
             else if (OP == 10) x[i] = gl::mul_pow2<12>(x[i]);
             else if (OP == 11) x[i] = gl::mul_pow2<84>(x[i]);
             else if (OP == 12) x[i] = gl::mul_pow2<48>(x[i]);
+            else if (OP == 13) x[i] = mul_v3(x[i], y[i]);
         }
     }
     uint64_t s = 0;
@@ -80,7 +99,7 @@ void run(const char *name) {
 }
 
 int main() {
-    run<0>("mul (u128)"); run<8>("mul (32-bit limbs)");
+    run<0>("mul (u128)"); run<8>("mul (32-bit limbs)"); run<13>("mul (rows)");
     run<1>("add (ref form)"); run<4>("add a1"); run<5>("add a2");
     run<2>("sub (ref form)"); run<6>("sub s1"); run<7>("sub s2 (asm)");
     run<9>("butterfly add+sub");
