@@ -222,3 +222,28 @@ def test_fri_restride_index_math():
                 assert start == (j * world + g) * chunk
                 assert start // per == parallel.fri_chunk_owner(j, g, world, N)
                 assert (start + chunk - 1) // per == start // per  # a chunk never straddles two pieces
+
+
+@pytest.mark.parametrize("world,N,length", [(2, 4, 64), (4, 4, 128), (8, 4, 256), (8, 2, 64), (8, 16, 1024), (4, 16, 256), (8, 8, 512)])
+def test_fri_restride_plan_routes_every_chunk(world, N, length):
+    """Simulate the uneven all-to-all from the per-rank plans: every rank must end up with exactly its chunk-major buffer
+    [j][i] = e[i0 + i + j*rc], and the send / receive split sizes of every pair of ranks must agree (no deadlock)."""
+    from winterfell_amd import parallel
+    e = np.arange(length, dtype=np.int64)
+    per, rc = length // world, length // N
+    chunk = rc // world
+    plans = [parallel.fri_restride_plan(world, r, N, per, chunk) for r in range(world)]
+    for h in range(world):
+        for g in range(world):
+            assert plans[h][1][g] == plans[g][2][h]                 # what h sends to g == what g expects from h
+    for g in range(world):
+        recv = []
+        for h in range(world):                                      # blocks arrive ordered by source rank
+            piece = e[h * per:(h + 1) * per]
+            for dest, start in plans[h][0]:
+                if dest == g:
+                    recv.append(piece[start:start + chunk])
+        got = np.concatenate(recv)
+        want = np.concatenate([e[j * rc + g * chunk:j * rc + (g + 1) * chunk] for j in range(N)])
+        assert np.array_equal(got, want)
+        assert sum(plans[g][2]) == N * chunk

@@ -182,9 +182,26 @@ def fri_chunk_owner(j, g, world, folding):
     return (j * world + g) // folding
 
 
+def fri_restride_plan(world, rank, folding, per, chunk):
+    """Index plan of the re-stride all-to-all for one rank.  `per` = elements per piece, `chunk` = elements per chunk
+    (per / folding).  Returns (send, in_split, out_split): send = [(dest, local_start)] in send-buffer order (by
+    destination, then chunk index j), in_split[g] / out_split[h] = elements sent to g / received from h."""
+    send, in_split = [], []
+    for g in range(world):
+        cnt = 0
+        for j in range(folding):
+            if fri_chunk_owner(j, g, world, folding) == rank:
+                send.append((g, (j * world + g) * chunk - rank * per))
+                cnt += 1
+        in_split.append(cnt * chunk)
+    out_split = [sum(1 for j in range(folding) if fri_chunk_owner(j, rank, world, folding) == h) * chunk for h in range(world)]
+    return send, in_split, out_split
+
+
 def fri_restride(piece, elem_words, world, rank, folding, group=None):
     """piece: this rank's contiguous length/G elements (torch uint64, flat).  Returns the rank's chunk-major buffer
-    [folding][rc/G] (flat): element (j, i) = e[i0 + i + j*rc] with i0 = rank * rc/G."""
+    [folding][rc/G] (flat): element (j, i) = e[i0 + i + j*rc] with i0 = rank * rc/G.  Received blocks arrive ordered by
+    source rank and, within a source, by j; the owner of chunk (j, g) is non-decreasing in j, so that IS chunk order."""
     import torch
     import torch.distributed as dist
     if world == 1:
@@ -192,17 +209,10 @@ def fri_restride(piece, elem_words, world, rank, folding, group=None):
     per = piece.numel() // elem_words                # length / G
     chunk = per // folding                           # rc / G elements
     cw = chunk * elem_words
-    # what this rank sends to each destination g: its chunks (j, g), j ascending
-    send, in_split = [], []
-    for g in range(world):
-        cnt = 0
-        for j in range(folding):
-            if fri_chunk_owner(j, g, world, folding) == rank:
-                start = (j * world + g) * chunk - rank * per
-                send.append(piece[start * elem_words:(start + chunk) * elem_words])
-                cnt += 1
-        in_split.append(cnt * cw)
-    out_split = [sum(1 for j in range(folding) if fri_chunk_owner(j, rank, world, folding) == h) * cw for h in range(world)]
+    plan, in_split, out_split = fri_restride_plan(world, rank, folding, per, chunk)
+    send = [piece[start * elem_words:(start + chunk) * elem_words] for _, start in plan]
+    in_split = [v * elem_words for v in in_split]
+    out_split = [v * elem_words for v in out_split]
     sendbuf = torch.cat(send) if send else piece[:0]
     recv = torch.empty(folding * cw, dtype=piece.dtype, device=piece.device)
     try:
