@@ -36,5 +36,11 @@ template <class F>
 __device__ __forceinline__ typename F::T series_at(const typename F::T *lo, const typename F::T *hi, uint32_t log_lo, uint64_t i) {
     return F::mul(lo[i & ((1ull << log_lo) - 1)], hi[i >> log_lo]);
 }
+// the same for indices known to fit 32 bits (every series here has at most 2^32 entries): 32-bit index arithmetic lets
+// the loads use the scalar-base + 32-bit-offset addressing form instead of 64-bit address arithmetic per element
+template <class F>
+__device__ __forceinline__ typename F::T series_at32(const typename F::T *lo, const typename F::T *hi, uint32_t log_lo, uint32_t i) {
+    return F::mul(lo[i & ((1u << log_lo) - 1u)], hi[i >> log_lo]);
+}
 
 }  // namespace

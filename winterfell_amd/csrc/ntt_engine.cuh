@@ -63,6 +63,22 @@ struct PassParams {
 #define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_WAVES_PER_EU, NTT_WAVES_PER_EU)))
 #endif
 
+// q = x / d, r = x % d for a wave-uniform divisor that is almost always 1 or a power of two (blowup, extension degree):
+// a runtime 64-bit division costs ~30-100 VALU instructions per lane, this costs a shift
+__device__ __forceinline__ void divmod_uniform(uint32_t x, uint32_t d, uint32_t &q, uint32_t &r) {
+    if (d == 1) {
+        q = x;
+        r = 0;
+    } else if ((d & (d - 1)) == 0) {
+        const uint32_t sh = 31u - (uint32_t)__builtin_clz(d);
+        q = x >> sh;
+        r = x & (d - 1);
+    } else {
+        q = x / d;
+        r = x - q * d;
+    }
+}
+
 template <class F, int LOG_A, int LOG_B, bool LAST>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typename F::T> p) {
     typedef typename F::T T;
@@ -95,8 +111,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     {
         const uint64_t cc = cc0 + t1;
         const bool active = cc < total_cols;
-        const uint64_t v = active ? cc / ncols : 0;
-        const uint64_t c = active ? cc % ncols : 0;
+        const uint32_t log_ncols = L - LOG_R;                // ncols is a power of two
+        const uint64_t v = active ? cc >> log_ncols : 0;
+        const uint64_t c = active ? cc & (ncols - 1) : 0;
         uint64_t base;
         if (!LAST) {
             const uint64_t rem = c & ((1ull << log_s) - 1);
@@ -111,8 +128,10 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 cr >>= p.log_r[q];
             }
         }
-        const uint64_t vs = v / p.src_div;
-        const T *src = p.src + (vs / p.src_inner) * p.src_vec_stride + (vs % p.src_inner) * p.src_inner_stride;
+        uint32_t vs, vq, vr;
+        divmod_uniform((uint32_t)v, p.src_div, vs, vr);
+        divmod_uniform(vs, p.src_inner, vq, vr);
+        const T *src = p.src + (uint64_t)vq * p.src_vec_stride + (uint64_t)vr * p.src_inner_stride;
         if (active) {
 #pragma unroll
             for (int a = 0; a < A; a++) {
@@ -120,7 +139,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 x[a] = F::load_norm(src[j * p.src_es]);
             }
             if (p.pre_lo != nullptr && p.pass == 0) {
-                const uint32_t u = (uint32_t)(v % p.pre_mod);
+                uint32_t uq, u;
+                divmod_uniform((uint32_t)v, p.pre_mod, uq, u);
                 const T *plo = p.pre_lo + u * p.pre_lo_stride, *phi = p.pre_hi + u * p.pre_hi_stride;
 #pragma unroll
                 for (int a = 0; a < A; a++) {
@@ -153,23 +173,25 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     const int q2 = (B > 1) ? tid / TC : 0;
     const uint64_t cc = cc0 + t2;
     if (cc >= total_cols) return;
-    const uint64_t v = cc / ncols;
-    const uint64_t c = cc % ncols;
-    T *dst = p.dst + (v / p.dst_inner) * p.dst_vec_stride + (v % p.dst_inner) * p.dst_inner_stride;
+    const uint64_t v = cc >> (L - LOG_R);
+    const uint64_t c = cc & (ncols - 1);
+    uint32_t dq, dr;
+    divmod_uniform((uint32_t)v, p.dst_inner, dq, dr);
+    T *dst = p.dst + (uint64_t)dq * p.dst_vec_stride + (uint64_t)dr * p.dst_inner_stride;
     const uint64_t rem = c & ((1ull << log_s) - 1);
     const uint64_t base_nl = ((c >> log_s) << (log_s + LOG_R)) + rem;
 
     auto emit = [&](T val, uint32_t kp) {
         if (!LAST) {
             if (kp != 0) {
-                const uint64_t e = ((uint64_t)kp * rem) << log_mult;
-                val = F::mul(val, series_at<F>(p.w_lo, p.w_hi, p.w_log_lo, e));
+                const uint32_t e = (kp * (uint32_t)rem) << log_mult;   // < n <= 2^32
+                val = F::mul(val, series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, e));
             }
             dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val;
         } else {
             uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
             if (p.inverse) k = (n - k) & (n - 1);
-            if (p.post_lo != nullptr) val = F::mul(val, series_at<F>(p.post_lo, p.post_hi, p.post_log_lo, k));
+            if (p.post_lo != nullptr) val = F::mul(val, series_at32<F>(p.post_lo, p.post_hi, p.post_log_lo, (uint32_t)k));
             else if (p.has_post_const) val = F::mul(val, p.post_const);
             dst[k * p.dst_es] = val;
         }
