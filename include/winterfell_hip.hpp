@@ -1,0 +1,439 @@
+// C++ host layer over the C ABI of libwinterfell_hip.so, mirroring the reference's (Rust) interfaces for the hot path:
+// the reference is compiled code and its toolchain is absent from the build image, so this header is the host side a
+// compiled caller links against (the Python package winterfell_amd/ is the same mirror for the test-suite).  It is
+// header only, needs nothing but <winterfell_hip.h>, and owns device memory through RAII buffers.
+//
+//   wf::Context                        one GPU + stream                                   (no reference counterpart)
+//   wf::DeviceBuffer                   HBM allocation with upload / download
+//   wf::fft::*                         math::fft::{evaluate_poly, interpolate_poly, ..._with_offset, get_twiddles}
+//                                      (math/src/fft/mod.rs:85-505) — same argument meaning, same panics as exceptions
+//   wf::ColMatrix / wf::RowMatrix      prover/src/matrix/{col_matrix.rs, row_matrix.rs}
+//   wf::MerkleTree                     crypto/src/merkle/mod.rs:91-458 (nodes in the reference's heap layout)
+//   wf::build_trace_commitment         prover/src/trace/trace_lde/default/mod.rs:245-282
+//   wf::FriProver                      fri/src/prover/mod.rs:100-239 (commit phase; the channel is a caller interface)
+//   wf::evaluate_constraints, wf::ood_frame, wf::deep_compose, wf::grind_query_seed  — SURVEY §8(f) N1–N3
+//
+// Field elements cross this layer exactly as they cross the C ABI: the reference's in-memory words (f64 / f62 Montgomery
+// u64, f128 canonical u128 as two u64), extension elements as consecutive base elements.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "winterfell_hip.h"
+
+namespace wf {
+
+enum class Field : int { F64 = WF_FIELD_F64, F128 = WF_FIELD_F128, F62 = WF_FIELD_F62 };
+enum class Hash : int {
+    Blake3_256 = WF_HASH_BLAKE3_256,
+    Rp64_256 = WF_HASH_RP64_256,
+    Sha3_256 = WF_HASH_SHA3_256,
+    RpJive64_256 = WF_HASH_RPJIVE64_256,
+    Rp62_248 = WF_HASH_RP62_248,
+    Blake3_192 = WF_HASH_BLAKE3_192
+};
+
+// words (u64) per base-field element
+inline uint32_t words(Field f) { return f == Field::F128 ? 2u : 1u; }
+
+// a non-zero status of the C ABI; the Rust shim would panic! / return Err at the same places
+class Error : public std::runtime_error {
+  public:
+    Error(int status, const char *where) : std::runtime_error(std::string(where) + ": " + wf_strerror(status)), status_(status) {}
+    int status() const { return status_; }
+
+  private:
+    int status_;
+};
+inline void check(int status, const char *where) {
+    if (status != WF_OK) throw Error(status, where);
+}
+
+class Context {
+  public:
+    explicit Context(int device = 0) { check(wf_ctx_create(device, &h_), "wf_ctx_create"); }
+    ~Context() {
+        if (h_) wf_ctx_destroy(h_);
+    }
+    Context(const Context &) = delete;
+    Context &operator=(const Context &) = delete;
+    wf_ctx *handle() const { return h_; }
+    void sync() { check(wf_ctx_sync(h_), "wf_ctx_sync"); }
+    void prof_enable(bool on) { check(wf_prof_enable(h_, on ? 1 : 0), "wf_prof_enable"); }
+    std::string prof_collect() {
+        std::vector<char> buf(1 << 16);
+        check(wf_prof_collect(h_, buf.data(), buf.size()), "wf_prof_collect");
+        return std::string(buf.data());
+    }
+
+  private:
+    wf_ctx *h_ = nullptr;
+};
+
+// HBM allocation of `n` u64 words (or bytes for digests), freed on destruction
+class DeviceBuffer {
+  public:
+    DeviceBuffer() = default;
+    DeviceBuffer(Context &ctx, size_t bytes) : ctx_(&ctx), bytes_(bytes) {
+        if (bytes) check(wf_malloc(ctx.handle(), bytes, &p_), "wf_malloc");
+    }
+    DeviceBuffer(Context &ctx, const void *host, size_t bytes) : DeviceBuffer(ctx, bytes) { upload(host, bytes); }
+    template <class T>
+    DeviceBuffer(Context &ctx, const std::vector<T> &host) : DeviceBuffer(ctx, host.data(), host.size() * sizeof(T)) {}
+    ~DeviceBuffer() { release(); }
+    DeviceBuffer(DeviceBuffer &&o) noexcept { *this = std::move(o); }
+    DeviceBuffer &operator=(DeviceBuffer &&o) noexcept {
+        if (this != &o) {
+            release();
+            ctx_ = o.ctx_;
+            p_ = o.p_;
+            bytes_ = o.bytes_;
+            o.p_ = nullptr;
+            o.bytes_ = 0;
+        }
+        return *this;
+    }
+    DeviceBuffer(const DeviceBuffer &) = delete;
+    DeviceBuffer &operator=(const DeviceBuffer &) = delete;
+
+    void *data() const { return p_; }
+    size_t bytes() const { return bytes_; }
+    void upload(const void *host, size_t bytes) { check(wf_memcpy_h2d(ctx_->handle(), p_, host, bytes), "wf_memcpy_h2d"); }
+    void download(void *host, size_t bytes, size_t offset = 0) const {
+        check(wf_memcpy_d2h(ctx_->handle(), host, (const uint8_t *)p_ + offset, bytes), "wf_memcpy_d2h");
+    }
+    template <class T>
+    std::vector<T> to_host() const {
+        std::vector<T> out(bytes_ / sizeof(T));
+        if (bytes_) download(out.data(), bytes_);
+        return out;
+    }
+    DeviceBuffer clone() const {
+        DeviceBuffer c(*ctx_, bytes_);
+        if (bytes_) check(wf_memcpy_d2d(ctx_->handle(), c.p_, p_, bytes_), "wf_memcpy_d2d");
+        return c;
+    }
+    Context &ctx() const { return *ctx_; }
+
+  private:
+    void release() {
+        if (p_) wf_free(ctx_->handle(), p_);
+        p_ = nullptr;
+    }
+    Context *ctx_ = nullptr;
+    void *p_ = nullptr;
+    size_t bytes_ = 0;
+};
+
+inline uint32_t log2_exact(uint64_t n, const char *what) {
+    if (n == 0 || (n & (n - 1))) throw std::invalid_argument(std::string("number of ") + what + " must be a power of 2");   // fft/mod.rs:90-93
+    uint32_t l = 0;
+    while ((1ull << l) < n) l++;
+    return l;
+}
+
+// ---- math::fft ---------------------------------------------------------------------------------------------------
+namespace fft {
+
+// fft::get_twiddles / get_inv_twiddles (mod.rs:455-505): n/2 elements
+inline DeviceBuffer get_twiddles(Context &ctx, Field f, uint64_t domain_size, bool inverse = false) {
+    const uint32_t log_n = log2_exact(domain_size, "domain size");
+    DeviceBuffer out(ctx, (domain_size / 2) * 8 * words(f));
+    check(wf_fft_get_twiddles(ctx.handle(), (int)f, log_n, inverse ? 1 : 0, out.data()), "wf_fft_get_twiddles");
+    return out;
+}
+// fft::evaluate_poly (mod.rs:85-112): in place over `num_elements` elements of extension degree `ext_degree`
+inline void evaluate_poly(DeviceBuffer &p, Field f, uint64_t num_elements, uint32_t ext_degree = 1, uint32_t batch = 1) {
+    check(wf_fft_evaluate_poly(p.ctx().handle(), (int)f, ext_degree, p.data(), log2_exact(num_elements, "coefficients"), batch), "wf_fft_evaluate_poly");
+}
+// fft::interpolate_poly (mod.rs:264-295)
+inline void interpolate_poly(DeviceBuffer &evals, Field f, uint64_t num_elements, uint32_t ext_degree = 1, uint32_t batch = 1) {
+    check(wf_fft_interpolate_poly(evals.ctx().handle(), (int)f, ext_degree, evals.data(), log2_exact(num_elements, "values"), batch), "wf_fft_interpolate_poly");
+}
+// fft::evaluate_poly_with_offset (mod.rs:168-211): `offset` = one base element (W words, internal form)
+inline DeviceBuffer evaluate_poly_with_offset(const DeviceBuffer &p, Field f, uint64_t num_elements, const uint64_t *offset,
+                                              uint64_t blowup_factor, uint32_t ext_degree = 1) {
+    DeviceBuffer out(p.ctx(), num_elements * blowup_factor * ext_degree * 8 * words(f));
+    check(wf_fft_evaluate_poly_with_offset(p.ctx().handle(), (int)f, ext_degree, p.data(), log2_exact(num_elements, "coefficients"), offset,
+                                           log2_exact(blowup_factor, "blowup factor"), out.data()), "wf_fft_evaluate_poly_with_offset");
+    return out;
+}
+// fft::interpolate_poly_with_offset (mod.rs:351-386): in place
+inline void interpolate_poly_with_offset(DeviceBuffer &evals, Field f, uint64_t num_elements, const uint64_t *offset, uint32_t ext_degree = 1) {
+    check(wf_fft_interpolate_poly_with_offset(evals.ctx().handle(), (int)f, ext_degree, evals.data(), log2_exact(num_elements, "values"), offset),
+          "wf_fft_interpolate_poly_with_offset");
+}
+
+}  // namespace fft
+
+// ---- air::PartitionOptions (air/src/options.rs:405-451) ----------------------------------------------------------------
+struct PartitionOptions {
+    uint32_t num_partitions = 1, hash_rate = 1;
+};
+
+// ---- crypto::MerkleTree (crypto/src/merkle/mod.rs) -----------------------------------------------------------------------
+class MerkleTree {
+  public:
+    // MerkleTree::new (mod.rs:116-135): `leaves` = num_leaves 32-byte digests in HBM.  TooFewLeaves /
+    // NumberOfLeavesNotPowerOfTwo surface as wf::Error with WF_ERR_TOO_FEW_LEAVES / WF_ERR_NOT_POWER_OF_TWO.
+    MerkleTree(Hash h, DeviceBuffer leaves, uint64_t num_leaves) : hash_(h), leaves_(std::move(leaves)), n_(num_leaves), nodes_(leaves_.ctx(), num_leaves * 32) {
+        check(wf_merkle_build(leaves_.ctx().handle(), (int)h, leaves_.data(), num_leaves, nodes_.data()), "wf_merkle_build");
+    }
+    MerkleTree(Hash h, DeviceBuffer leaves, DeviceBuffer nodes, uint64_t num_leaves)
+        : hash_(h), leaves_(std::move(leaves)), n_(num_leaves), nodes_(std::move(nodes)) {}
+    uint64_t num_leaves() const { return n_; }
+    uint32_t depth() const { return log2_exact(n_, "leaves"); }
+    const DeviceBuffer &nodes_device() const { return nodes_; }
+    const DeviceBuffer &leaves_device() const { return leaves_; }
+    // heap layout: root at 1, children of i at 2i / 2i+1, nodes[0] = default digest (mod.rs:344-368)
+    const std::vector<uint8_t> &nodes() const {
+        if (h_nodes_.empty()) h_nodes_ = nodes_.to_host<uint8_t>();
+        return h_nodes_;
+    }
+    const std::vector<uint8_t> &leaves() const {
+        if (h_leaves_.empty()) h_leaves_ = leaves_.to_host<uint8_t>();
+        return h_leaves_;
+    }
+    std::vector<uint8_t> root() const { return std::vector<uint8_t>(nodes().begin() + 32, nodes().begin() + 64); }
+    // MerkleTree::prove (mod.rs:193-215): [leaf, sibling leaf, then the sibling node of every level up to the root]
+    std::vector<std::vector<uint8_t>> prove(uint64_t index) const {
+        if (index >= n_) throw std::out_of_range("LeafIndexOutOfBounds");
+        auto digest = [](const std::vector<uint8_t> &v, uint64_t i) { return std::vector<uint8_t>(v.begin() + 32 * i, v.begin() + 32 * (i + 1)); };
+        std::vector<std::vector<uint8_t>> out{digest(leaves(), index), digest(leaves(), index ^ 1)};
+        for (uint64_t i = (index + n_) >> 1; i > 1; i >>= 1) out.push_back(digest(nodes(), i ^ 1));
+        return out;
+    }
+
+  private:
+    Hash hash_;
+    DeviceBuffer leaves_;
+    uint64_t n_;
+    DeviceBuffer nodes_;
+    mutable std::vector<uint8_t> h_nodes_, h_leaves_;
+};
+
+// ---- prover::matrix --------------------------------------------------------------------------------------------------------
+// ColMatrix (col_matrix.rs:28-62): num_cols columns of num_rows elements, column k at k * col_stride base elements
+struct ColMatrix {
+    DeviceBuffer data;
+    Field field = Field::F64;
+    uint32_t num_cols = 0, ext_degree = 1;
+    uint64_t num_rows = 0;
+    uint64_t col_stride() const { return num_rows * ext_degree; }
+    // ColMatrix::interpolate_columns (col_matrix.rs:192-202): returns a new matrix of coefficients
+    ColMatrix interpolate_columns() const {
+        ColMatrix out{data.clone(), field, num_cols, ext_degree, num_rows};
+        check(wf_interpolate_columns(data.ctx().handle(), (int)field, ext_degree, out.data.data(), num_cols, col_stride(), log2_exact(num_rows, "rows")),
+              "wf_interpolate_columns");
+        return out;
+    }
+};
+
+// RowMatrix (row_matrix.rs:28-41): data[row * row_width + col], row_width = 8 * ceil(base columns / 8)
+struct RowMatrix {
+    DeviceBuffer data;
+    Field field = Field::F64;
+    uint64_t num_rows = 0, row_width = 0;
+    uint32_t elements_per_row = 0, ext_degree = 1;
+    // RowMatrix::evaluate_polys_over::<8> (row_matrix.rs:84-100)
+    static RowMatrix evaluate_polys_over(const ColMatrix &polys, uint64_t blowup, const uint64_t *domain_offset) {
+        Context &ctx = polys.data.ctx();
+        RowMatrix m;
+        m.field = polys.field;
+        m.ext_degree = polys.ext_degree;
+        m.num_rows = polys.num_rows * blowup;
+        m.row_width = wf_row_width(polys.num_cols, polys.ext_degree);
+        m.elements_per_row = polys.num_cols * polys.ext_degree;
+        m.data = DeviceBuffer(ctx, m.num_rows * m.row_width * 8 * words(m.field));
+        check(wf_evaluate_polys_over(ctx.handle(), (int)m.field, m.ext_degree, polys.data.data(), polys.num_cols, polys.col_stride(),
+                                     log2_exact(polys.num_rows, "rows"), log2_exact(blowup, "blowup factor"), domain_offset, m.data.data()),
+              "wf_evaluate_polys_over");
+        return m;
+    }
+    // RowMatrix::commit_to_rows (row_matrix.rs:184-228)
+    MerkleTree commit_to_rows(Hash h, PartitionOptions po = {}) const {
+        Context &ctx = data.ctx();
+        DeviceBuffer leaves(ctx, num_rows * 32);
+        check(wf_hash_rows(ctx.handle(), (int)h, (int)field, ext_degree, data.data(), num_rows, row_width, elements_per_row, po.num_partitions,
+                           po.hash_rate, leaves.data()), "wf_hash_rows");
+        return MerkleTree(h, std::move(leaves), num_rows);
+    }
+    // TraceLde::query row gather (trace_lde/default/mod.rs:199-215)
+    std::vector<uint64_t> rows(const std::vector<uint64_t> &positions) const {
+        std::vector<uint64_t> out(positions.size() * elements_per_row * words(field));
+        if (!positions.empty())
+            check(wf_rows_fetch(data.ctx().handle(), data.data(), row_width, elements_per_row, 8 * words(field), positions.data(), (uint32_t)positions.size(),
+                                out.data()), "wf_rows_fetch");
+        return out;
+    }
+};
+
+// build_trace_commitment (trace_lde/default/mod.rs:245-282): interpolate -> coset LDE -> row hashes -> Merkle tree in one
+// library call.  Returns (trace_lde, tree, trace_polys).
+struct TraceCommitment {
+    RowMatrix lde;
+    MerkleTree tree;
+    ColMatrix polys;
+};
+inline TraceCommitment build_trace_commitment(Hash h, const ColMatrix &trace, uint64_t blowup, const uint64_t *domain_offset,
+                                              PartitionOptions po = {}, bool skip_interpolate = false) {
+    Context &ctx = trace.data.ctx();
+    ColMatrix polys{trace.data.clone(), trace.field, trace.num_cols, trace.ext_degree, trace.num_rows};
+    RowMatrix lde;
+    lde.field = trace.field;
+    lde.ext_degree = trace.ext_degree;
+    lde.num_rows = trace.num_rows * blowup;
+    lde.row_width = wf_row_width(trace.num_cols, trace.ext_degree);
+    lde.elements_per_row = trace.num_cols * trace.ext_degree;
+    lde.data = DeviceBuffer(ctx, lde.num_rows * lde.row_width * 8 * words(trace.field));
+    DeviceBuffer leaves(ctx, lde.num_rows * 32), nodes(ctx, lde.num_rows * 32);
+    check(wf_build_trace_commitment(ctx.handle(), (int)h, (int)trace.field, trace.ext_degree, polys.data.data(), trace.num_cols, trace.col_stride(),
+                                    log2_exact(trace.num_rows, "rows"), log2_exact(blowup, "blowup factor"), domain_offset, po.num_partitions,
+                                    po.hash_rate, skip_interpolate ? 1 : 0, lde.data.data(), leaves.data(), nodes.data(), nullptr),
+          "wf_build_trace_commitment");
+    return TraceCommitment{std::move(lde), MerkleTree(h, std::move(leaves), std::move(nodes), trace.num_rows * blowup), std::move(polys)};
+}
+
+// ---- fri::FriProver (commit phase) -------------------------------------------------------------------------------------------
+// fri::ProverChannel (fri/src/prover/channel.rs:24-50): the host Fiat-Shamir transcript, supplied by the caller
+struct ProverChannel {
+    virtual ~ProverChannel() = default;
+    virtual void commit_fri_layer(const uint8_t root[32]) = 0;
+    virtual std::vector<uint64_t> draw_fri_alpha() = 0;   // one element of the extension field (ext_degree * W words)
+};
+
+struct FriOptions {   // fri/src/options.rs:13-93
+    uint64_t blowup_factor, folding_factor, remainder_max_degree;
+    uint64_t num_fri_layers(uint64_t domain_size) const {
+        uint64_t result = 0;
+        const uint64_t max_rem = (remainder_max_degree + 1) * blowup_factor;
+        while (domain_size > max_rem) {
+            domain_size /= folding_factor;
+            result++;
+        }
+        return result;
+    }
+};
+
+struct FriLayer {   // fri/src/prover/mod.rs:111-115
+    MerkleTree commitment;
+    DeviceBuffer evaluations;   // transposed: [len / folding][folding * ext_degree * W]
+};
+
+class FriProver {
+  public:
+    FriProver(FriOptions o, Hash h, Field f, uint32_t ext_degree, std::vector<uint64_t> domain_offset)
+        : opts_(o), hash_(h), field_(f), D_(ext_degree), offset_(std::move(domain_offset)) {}
+    // FriProver::build_layers (mod.rs:179-199); `evaluations` is consumed
+    void build_layers(ProverChannel &channel, DeviceBuffer evaluations, uint64_t length) {
+        if (!layers_.empty()) throw std::logic_error("a prior proof generation request has not been completed yet");
+        Context &ctx = evaluations.ctx();
+        const uint32_t ew = D_ * words(field_);
+        const uint64_t N = opts_.folding_factor;
+        for (uint64_t k = opts_.num_fri_layers(length); k > 0; k--) {
+            const uint32_t log_len = log2_exact(length, "evaluations");
+            const uint64_t rows = length / N;
+            DeviceBuffer transposed(ctx, rows * N * ew * 8), leaves(ctx, rows * 32), nodes(ctx, rows * 32);
+            uint8_t root[32];
+            check(wf_fri_layer_commit(ctx.handle(), (int)hash_, (int)field_, D_, evaluations.data(), log_len, (uint32_t)N, transposed.data(), leaves.data(),
+                                      nodes.data(), root), "wf_fri_layer_commit");
+            channel.commit_fri_layer(root);
+            const std::vector<uint64_t> alpha = channel.draw_fri_alpha();
+            DeviceBuffer folded(ctx, rows * ew * 8);
+            check(wf_fri_apply_drp(ctx.handle(), (int)field_, D_, transposed.data(), log_len, (uint32_t)N, offset_.data(), alpha.data(), folded.data()),
+                  "wf_fri_apply_drp");
+            layers_.push_back(FriLayer{MerkleTree(hash_, std::move(leaves), std::move(nodes), rows), std::move(transposed)});
+            evaluations = std::move(folded);
+            length = rows;
+        }
+        set_remainder(channel, evaluations, length);
+    }
+    const std::vector<FriLayer> &layers() const { return layers_; }
+    // reversed coefficients of the remainder polynomial (mod.rs:230-239), ext_degree * W words each
+    const std::vector<uint64_t> &remainder_poly() const { return remainder_; }
+
+  private:
+    void set_remainder(ProverChannel &channel, DeviceBuffer &ev, uint64_t length) {
+        Context &ctx = ev.ctx();
+        const uint32_t ew = D_ * words(field_);
+        if (length > 1) fft::interpolate_poly_with_offset(ev, field_, length, offset_.data(), D_);
+        std::vector<uint64_t> coeffs = ev.to_host<uint64_t>();
+        const uint64_t size = length / opts_.blowup_factor;
+        remainder_.assign(size * ew, 0);
+        for (uint64_t i = 0; i < size; i++) std::memcpy(&remainder_[i * ew], &coeffs[(size - 1 - i) * ew], ew * 8);
+        DeviceBuffer d_rem(ctx, remainder_), d_out(ctx, 32);
+        check(wf_hash_elements_batch(ctx.handle(), (int)hash_, (int)field_, d_rem.data(), 1, size * D_, (uint32_t)(size * D_), d_out.data()),
+              "wf_hash_elements_batch");
+        uint8_t com[32];
+        d_out.download(com, 32);
+        channel.commit_fri_layer(com);
+    }
+    FriOptions opts_;
+    Hash hash_;
+    Field field_;
+    uint32_t D_;
+    std::vector<uint64_t> offset_;
+    std::vector<FriLayer> layers_;
+    std::vector<uint64_t> remainder_;
+};
+
+// ---- SURVEY §8(f) N1–N3 ------------------------------------------------------------------------------------------------------
+// ProverChannel::grind_query_seed (prover/src/channel.rs:169-185): smallest nonce >= 1 with enough trailing zeros
+inline uint64_t grind_query_seed(Context &ctx, Hash h, const uint8_t seed[32], uint32_t grinding_factor) {
+    uint64_t nonce = 0;
+    check(wf_grind(ctx.handle(), (int)h, seed, grinding_factor, 1, ~0ull - 1, &nonce), "wf_grind");
+    return nonce;
+}
+
+// TracePolyTable::get_ood_frame / CompositionPoly::get_ood_frame: all columns at the given points;
+// out[point][column] elements of ext_degree * W words
+inline std::vector<uint64_t> evaluate_columns_at(const ColMatrix &polys, const std::vector<uint64_t> &points, uint32_t num_points, uint32_t ext_degree) {
+    std::vector<uint64_t> out((size_t)num_points * polys.num_cols * ext_degree * words(polys.field));
+    check(wf_polys_evaluate_at(polys.data.ctx().handle(), (int)polys.field, polys.ext_degree, ext_degree, polys.data.data(), polys.num_cols, polys.col_stride(),
+                               log2_exact(polys.num_rows, "rows"), points.data(), num_points, out.data()), "wf_polys_evaluate_at");
+    return out;
+}
+
+// DeepCompositionPoly::add_trace_polys (prover/src/composer/mod.rs:67-169) -> coefficients (num_rows elements over E)
+inline DeviceBuffer deep_compose(const ColMatrix &main_polys, const ColMatrix *aux_polys, const ColMatrix &quotient_polys, uint32_t ext_degree,
+                                 const std::vector<uint64_t> &z, const std::vector<uint64_t> &cc_trace, const std::vector<uint64_t> &cc_constraints) {
+    Context &ctx = main_polys.data.ctx();
+    DeviceBuffer out(ctx, main_polys.num_rows * ext_degree * 8 * words(main_polys.field));
+    check(wf_deep_compose(ctx.handle(), (int)main_polys.field, ext_degree, main_polys.data.data(), main_polys.num_cols, main_polys.col_stride(),
+                          aux_polys ? aux_polys->data.data() : nullptr, aux_polys ? aux_polys->num_cols : 0, aux_polys ? aux_polys->col_stride() : 0,
+                          quotient_polys.data.data(), quotient_polys.num_cols, quotient_polys.col_stride(), log2_exact(main_polys.num_rows, "rows"), z.data(),
+                          cc_trace.data(), cc_constraints.data(), out.data()), "wf_deep_compose");
+    return out;
+}
+
+// Assertion::single + DefaultConstraintEvaluator::evaluate for the built-in AIRs (wf_evaluate_constraints)
+struct Assertion {
+    uint32_t column;
+    uint64_t step;
+    std::vector<uint64_t> value;   // one base element (W words)
+};
+inline DeviceBuffer evaluate_constraints(int air, const RowMatrix &trace_lde, uint64_t trace_length, uint64_t lde_blowup, uint64_t ce_blowup,
+                                         const uint64_t *domain_offset, uint32_t ext_degree, const std::vector<uint64_t> &cc_transition,
+                                         const std::vector<Assertion> &assertions, const std::vector<uint64_t> &cc_boundary) {
+    Context &ctx = trace_lde.data.ctx();
+    const uint32_t W = words(trace_lde.field);
+    std::vector<uint32_t> cols;
+    std::vector<uint64_t> steps, vals;
+    for (const Assertion &a : assertions) {
+        cols.push_back(a.column);
+        steps.push_back(a.step);
+        vals.insert(vals.end(), a.value.begin(), a.value.begin() + W);
+    }
+    DeviceBuffer out(ctx, trace_length * ce_blowup * ext_degree * 8 * W);
+    check(wf_evaluate_constraints(ctx.handle(), air, (int)trace_lde.field, ext_degree, trace_lde.data.data(), trace_lde.row_width,
+                                  log2_exact(trace_length, "rows"), log2_exact(lde_blowup, "blowup factor"), log2_exact(ce_blowup, "blowup factor"),
+                                  domain_offset, cc_transition.data(), (uint32_t)assertions.size(), cols.data(), steps.data(), vals.data(), cc_boundary.data(),
+                                  out.data()), "wf_evaluate_constraints");
+    return out;
+}
+
+}  // namespace wf

@@ -1,0 +1,220 @@
+// Parity of the C++ host layer (include/winterfell_hip.hpp) against the CPU oracle (liboracle.so, test infrastructure):
+// the compiled-language counterpart of tests/test_gpu_*.py.  Built and run by tests/test_gpu_cpp_host.py on a GPU box.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "../../include/winterfell_hip.hpp"
+
+extern "C" {
+// field-generic oracle instantiation for f64 (oracle/field_f64t.c) and the f64 helpers
+uint64_t or_f64_new1(uint64_t a);
+void or_f64t_evaluate_poly(uint64_t *p, uint64_t n, unsigned D);
+void or_f64t_interpolate_poly(uint64_t *p, uint64_t n, unsigned D);
+void or_f64t_evaluate_poly_with_offset(const uint64_t *p, uint64_t n, unsigned D, const uint64_t *offset, uint64_t blowup, uint64_t *out);
+int or_f64t_build_trace_commitment(int hasher, uint64_t *trace, uint64_t c, uint64_t n, unsigned D, uint64_t blowup, const uint64_t *offset,
+                                   uint64_t num_partitions, uint64_t hash_rate, uint64_t *lde, uint8_t *leaves, uint8_t *nodes);
+void or_f64t_transpose_slice(const uint64_t *src, uint64_t len, unsigned D, uint64_t N, uint64_t *dst);
+int or_f64t_fri_layer_commit(int hasher, const uint64_t *tr, uint64_t rows, unsigned D, uint64_t N, uint8_t *leaves, uint8_t *nodes);
+void or_f64t_apply_drp(const uint64_t *values, uint64_t rows, unsigned D, uint64_t N, const uint64_t *offset, const uint64_t *alpha, uint64_t *out);
+void or_fri_remainder(int hasher, uint64_t *evals, uint64_t len, unsigned D, uint64_t offset, uint64_t blowup, uint64_t *rem, uint8_t com[32]);
+void or_f64t_fib_small_build_trace(uint64_t n, uint64_t *trace);
+int or_f64t_evaluate_constraints(int air, const uint64_t *lde, uint64_t row_width, uint64_t n, uint64_t lde_blowup, uint64_t ce_blowup,
+                                 const uint64_t *offset, unsigned D, const uint64_t *cc_t, uint64_t num_assert, const uint64_t *a_col,
+                                 const uint64_t *a_step, const uint64_t *a_val, const uint64_t *cc_b, uint64_t *out);
+void or_f64t_evaluate_columns_at(const uint64_t *polys, uint64_t c, uint64_t n, unsigned pD, const uint64_t *x, unsigned D, uint64_t *out);
+void or_f64t_deep_compose(const uint64_t *main_polys, uint64_t c_main, const uint64_t *aux, uint64_t c_aux, const uint64_t *quot, uint64_t c_q,
+                          uint64_t n, unsigned D, const uint64_t *z, const uint64_t *cc_t, const uint64_t *cc_c, const uint64_t *otc,
+                          const uint64_t *otn, const uint64_t *oqc, const uint64_t *oqn, uint64_t *out);
+uint64_t or_row_width(uint64_t base_cols);
+// DefaultRandomCoin restatement (oracle/fri.c)
+uint64_t or_coin_sizeof(void);
+void or_coin_new(void *c, int hasher, const uint64_t *seed, uint64_t n);
+void or_coin_reseed(void *c, const uint8_t data[32]);
+int or_coin_draw(void *c, unsigned D, uint64_t *out);
+void or_coin_seed(const void *c, uint8_t out[32]);
+uint64_t or_coin_grind(const void *c, uint32_t factor, uint64_t limit);
+}
+
+static int failures = 0;
+#define EXPECT(cond, what)                                  \
+    do {                                                    \
+        if (!(cond)) {                                      \
+            printf("FAIL %s (%s:%d)\n", what, __FILE__, __LINE__); \
+            failures++;                                     \
+        } else {                                            \
+            printf("ok   %s\n", what);                      \
+        }                                                   \
+    } while (0)
+
+static const uint64_t P = 0xffffffff00000001ull;
+static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
+static uint64_t rnd() {
+    rng_state ^= rng_state << 13;
+    rng_state ^= rng_state >> 7;
+    rng_state ^= rng_state << 17;
+    return rng_state % P;   // every canonical u64 < p is a valid internal (Montgomery) word
+}
+static std::vector<uint64_t> rand_vec(size_t n) {
+    std::vector<uint64_t> v(n);
+    for (auto &x : v) x = rnd();
+    return v;
+}
+
+// oracle-backed Fiat-Shamir channel (fri::DefaultProverChannel)
+struct OracleChannel : wf::ProverChannel {
+    std::vector<uint8_t> coin;
+    unsigned D;
+    std::vector<std::vector<uint8_t>> commitments;
+    OracleChannel(int hasher, unsigned D_) : coin(or_coin_sizeof()), D(D_) { or_coin_new(coin.data(), hasher, nullptr, 0); }
+    void commit_fri_layer(const uint8_t root[32]) override {
+        commitments.emplace_back(root, root + 32);
+        or_coin_reseed(coin.data(), root);
+    }
+    std::vector<uint64_t> draw_fri_alpha() override {
+        std::vector<uint64_t> a(D);
+        if (or_coin_draw(coin.data(), D, a.data())) abort();
+        return a;
+    }
+};
+
+int main() {
+    wf::Context ctx(0);
+    const wf::Field F = wf::Field::F64;
+    const uint64_t offset = or_f64_new1(7);
+
+    // ---- math::fft -----------------------------------------------------------------------------------------------------
+    {
+        const uint64_t n = 1 << 10;
+        const unsigned D = 2;
+        std::vector<uint64_t> p = rand_vec(n * D), want = p;
+        wf::DeviceBuffer d(ctx, p);
+        wf::fft::evaluate_poly(d, F, n, D);
+        or_f64t_evaluate_poly(want.data(), n, D);
+        EXPECT(d.to_host<uint64_t>() == want, "fft::evaluate_poly (quadratic extension, 2^10)");
+        wf::fft::interpolate_poly(d, F, n, D);
+        EXPECT(d.to_host<uint64_t>() == p, "fft::interpolate_poly inverts it");
+        std::vector<uint64_t> lde(n * 8 * D);
+        or_f64t_evaluate_poly_with_offset(p.data(), n, D, &offset, 8, lde.data());
+        wf::DeviceBuffer e = wf::fft::evaluate_poly_with_offset(d, F, n, &offset, 8, D);
+        EXPECT(e.to_host<uint64_t>() == lde, "fft::evaluate_poly_with_offset (blowup 8)");
+        bool threw = false;
+        try {
+            wf::fft::evaluate_poly(d, F, 1000, D);
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        EXPECT(threw, "non power-of-two length is rejected (fft/mod.rs:90-93)");
+    }
+
+    // ---- build_trace_commitment + MerkleTree (Blake3_256 and Rp64_256, partitions) ---------------------------------------------
+    for (int hasher = 0; hasher < 2; hasher++) {
+        const uint64_t n = 1 << 8, c = 12, blowup = 8, N = n * blowup, parts = hasher == 0 ? 4 : 1;
+        std::vector<uint64_t> trace = rand_vec(c * n), o_trace = trace;
+        const uint64_t rw = or_row_width(c);
+        std::vector<uint64_t> o_lde(N * rw);
+        std::vector<uint8_t> o_leaves(N * 32), o_nodes(N * 32);
+        or_f64t_build_trace_commitment(hasher, o_trace.data(), c, n, 1, blowup, &offset, parts, 1, o_lde.data(), o_leaves.data(), o_nodes.data());
+        wf::ColMatrix cm{wf::DeviceBuffer(ctx, trace), F, (uint32_t)c, 1, n};
+        wf::TraceCommitment tc = wf::build_trace_commitment((wf::Hash)hasher, cm, blowup, &offset, wf::PartitionOptions{(uint32_t)parts, 1});
+        EXPECT(tc.polys.data.to_host<uint64_t>() == o_trace, hasher ? "trace polys (Rp64_256 run)" : "trace polys (Blake3_256 run)");
+        EXPECT(tc.lde.data.to_host<uint64_t>() == o_lde, "row-major trace LDE");
+        EXPECT(tc.tree.leaves() == o_leaves, "row digests");
+        EXPECT(tc.tree.nodes() == o_nodes, "Merkle nodes (heap layout)");
+        auto proof = tc.tree.prove(5);
+        EXPECT(proof.size() == tc.tree.depth() + 1 && std::memcmp(proof[1].data(), &o_leaves[4 * 32], 32) == 0 &&
+                   std::memcmp(proof.back().data(), &o_nodes[3 * 32], 32) == 0, "MerkleTree::prove path");
+        std::vector<uint64_t> rows = tc.lde.rows({3, 700});
+        EXPECT(std::memcmp(rows.data(), &o_lde[3 * rw], c * 8) == 0 && std::memcmp(&rows[c], &o_lde[700 * rw], c * 8) == 0, "TraceLde::query rows");
+        // two-step path: evaluate_polys_over + commit_to_rows == the fused call
+        wf::RowMatrix lde2 = wf::RowMatrix::evaluate_polys_over(tc.polys, blowup, &offset);
+        wf::MerkleTree t2 = lde2.commit_to_rows((wf::Hash)hasher, wf::PartitionOptions{(uint32_t)parts, 1});
+        EXPECT(t2.nodes() == o_nodes, "RowMatrix::commit_to_rows");
+    }
+    {
+        bool threw = false;
+        try {
+            wf::MerkleTree t(wf::Hash::Blake3_256, wf::DeviceBuffer(ctx, std::vector<uint8_t>(3 * 32)), 3);
+        } catch (const wf::Error &e) {
+            threw = e.status() == WF_ERR_NOT_POWER_OF_TWO;
+        }
+        EXPECT(threw, "MerkleTree: NumberOfLeavesNotPowerOfTwo");
+    }
+
+    // ---- FriProver::build_layers with the oracle's DefaultProverChannel -----------------------------------------------------------
+    {
+        const unsigned D = 2;
+        const uint64_t len = 1 << 12, N = 4, blowup = 8;
+        std::vector<uint64_t> poly = rand_vec((len / blowup) * D), ev(len * D);
+        or_f64t_evaluate_poly_with_offset(poly.data(), len / blowup, D, &offset, blowup, ev.data());
+        OracleChannel chan(0, D), ochan(0, D);
+        wf::FriProver prover(wf::FriOptions{blowup, N, 7}, wf::Hash::Blake3_256, F, D, {offset});
+        prover.build_layers(chan, wf::DeviceBuffer(ctx, ev), len);
+        std::vector<uint64_t> cur = ev;
+        uint64_t length = len;
+        bool ok = true;
+        for (size_t k = 0; k < prover.layers().size(); k++) {
+            const uint64_t rows = length / N;
+            std::vector<uint64_t> tr(length * D), folded(rows * D);
+            std::vector<uint8_t> leaves(rows * 32), nodes(rows * 32);
+            or_f64t_transpose_slice(cur.data(), length, D, N, tr.data());
+            or_f64t_fri_layer_commit(0, tr.data(), rows, D, N, leaves.data(), nodes.data());
+            ochan.commit_fri_layer(&nodes[32]);
+            std::vector<uint64_t> alpha = ochan.draw_fri_alpha();
+            or_f64t_apply_drp(tr.data(), rows, D, N, &offset, alpha.data(), folded.data());
+            ok = ok && prover.layers()[k].commitment.nodes() == nodes && prover.layers()[k].evaluations.to_host<uint64_t>() == tr;
+            cur = folded;
+            length = rows;
+        }
+        std::vector<uint64_t> rem((length / blowup) * D);
+        uint8_t com[32];
+        or_fri_remainder(0, cur.data(), length, D, offset, blowup, rem.data(), com);
+        EXPECT(ok && prover.layers().size() == 3, "FriProver layers: nodes and transposed evaluations");
+        EXPECT(prover.remainder_poly() == rem && std::memcmp(chan.commitments.back().data(), com, 32) == 0, "FRI remainder polynomial and its commitment");
+    }
+
+    // ---- fib_small: constraint evaluation, OOD frame, DEEP composition, grinding ------------------------------------------------------
+    {
+        const unsigned D = 2;
+        const uint64_t n = 1 << 8, blowup = 8, ce_blowup = 2, N = n * blowup;
+        std::vector<uint64_t> trace(2 * n);
+        or_f64t_fib_small_build_trace(n, trace.data());
+        wf::ColMatrix cm{wf::DeviceBuffer(ctx, trace), F, 2, 1, n};
+        wf::TraceCommitment tc = wf::build_trace_commitment(wf::Hash::Blake3_256, cm, blowup, &offset);
+        std::vector<uint64_t> cc_t = rand_vec(2 * D), cc_b = rand_vec(3 * D);
+        const uint64_t one = or_f64_new1(1), result = trace[2 * n - 1];
+        std::vector<wf::Assertion> as{{0, 0, {one}}, {1, 0, {one}}, {1, n - 1, {result}}};
+        wf::DeviceBuffer ev = wf::evaluate_constraints(WF_AIR_FIB_SMALL, tc.lde, n, blowup, ce_blowup, &offset, D, cc_t, as, cc_b);
+        std::vector<uint64_t> o_lde = tc.lde.data.to_host<uint64_t>(), want(n * ce_blowup * D);
+        const uint64_t a_col[3] = {0, 1, 1}, a_step[3] = {0, 0, n - 1}, a_val[3] = {one, one, result};
+        or_f64t_evaluate_constraints(0, o_lde.data(), tc.lde.row_width, n, blowup, ce_blowup, &offset, D, cc_t.data(), 3, a_col, a_step, a_val,
+                                     cc_b.data(), want.data());
+        EXPECT(ev.to_host<uint64_t>() == want, "evaluate_constraints (FibSmall, quadratic extension)");
+        // composition poly (1 column) + OOD frames + DEEP
+        wf::fft::interpolate_poly_with_offset(ev, F, n * ce_blowup, &offset, D);
+        std::vector<uint64_t> comp = ev.to_host<uint64_t>();
+        comp.resize(n * D);
+        wf::ColMatrix quot{wf::DeviceBuffer(ctx, comp), F, 1, D, n};
+        std::vector<uint64_t> z = rand_vec(D), cct = rand_vec(2 * D), ccq = rand_vec(1 * D);
+        std::vector<uint64_t> frame = wf::evaluate_columns_at(tc.polys, z, 1, D), o_frame(2 * D);
+        std::vector<uint64_t> polys_h = tc.polys.data.to_host<uint64_t>();
+        or_f64t_evaluate_columns_at(polys_h.data(), 2, n, 1, z.data(), D, o_frame.data());
+        EXPECT(frame == o_frame, "out-of-domain trace frame (evaluate_columns_at)");
+        wf::DeviceBuffer deep = wf::deep_compose(tc.polys, nullptr, quot, D, z, cct, ccq);
+        std::vector<uint64_t> o_deep(n * D), zeros(4 * D, 0);
+        or_f64t_deep_compose(polys_h.data(), 2, nullptr, 0, comp.data(), 1, n, D, z.data(), cct.data(), ccq.data(), zeros.data(), zeros.data(), zeros.data(),
+                             zeros.data(), o_deep.data());
+        EXPECT(deep.to_host<uint64_t>() == o_deep, "DEEP composition polynomial");
+        // grinding against the oracle coin
+        std::vector<uint8_t> coin(or_coin_sizeof());
+        or_coin_new(coin.data(), 0, cc_t.data(), 2);
+        uint8_t seed[32];
+        or_coin_seed(coin.data(), seed);
+        EXPECT(wf::grind_query_seed(ctx, wf::Hash::Blake3_256, seed, 12) == or_coin_grind(coin.data(), 12, 1ull << 30), "grind_query_seed (factor 12)");
+        (void)N;
+    }
+
+    printf(failures ? "FAILED: %d check(s)\n" : "ALL OK\n", failures);
+    return failures ? 1 : 0;
+}
