@@ -143,7 +143,10 @@ def main():
             piece = ctx.to_device(np.random.default_rng(100 + rank).integers(0, fields.M, ((1 << 24) // world) * 2, dtype=np.uint64))
             fopts = wfri.FriOptions(8, 4, 31)
             fbackend = parallel.HipFriBackend(crypto.Blake3_256, fields.f64, 2, ctx)
-            run = lambda: parallel.sharded_fri_build_layers(fbackend, fopts, _Chan(), piece, 2, min_rows_per_rank=1 << 12)
+            # equal-size all-gather re-stride here (the uneven all-to-all variant is exercised by the gloo tests): a size
+            # mismatch in an optional leg must never be able to hang the headline run
+            xchg = lambda pc, ew, nf: parallel.fri_restride_allgather(pc, ew, world, rank, nf)
+            run = lambda: parallel.sharded_fri_build_layers(fbackend, fopts, _Chan(), piece, 2, min_rows_per_rank=1 << 12, exchange=xchg)
             run()
             ts = []
             for _ in range(3):

@@ -167,7 +167,9 @@ def _fri_worker(rank, world, port, hasher_id, out_dir):
     per = ev.size // world
     piece = torch.from_numpy(ev[rank * per:(rank + 1) * per].copy())
     chan = oracle.ProverChannel(hasher_id, D)
-    res = parallel.sharded_fri_build_layers(_OracleFriBackend(hasher_id, D), opts, chan, piece, D)
+    # world 4 runs the all-gather re-stride variant, the others the uneven all-to-all
+    xchg = (lambda pc, ew, nf: parallel.fri_restride_allgather(pc, ew, world, rank, nf)) if world == 4 else None
+    res = parallel.sharded_fri_build_layers(_OracleFriBackend(hasher_id, D), opts, chan, piece, D, exchange=xchg)
     np.savez(os.path.join(out_dir, "fri%d.npz" % rank), nlayers=len(res["layers"]), remainder=res["remainder"],
              commitments=np.stack(chan.commitments), ntail=len(res["tail"]),
              **{"rows%d" % k: l["rows"].numpy() for k, l in enumerate(res["layers"])},

@@ -198,6 +198,17 @@ def fri_restride_plan(world, rank, folding, per, chunk):
     return send, in_split, out_split
 
 
+def fri_restride_allgather(piece, elem_words, world, rank, folding, group=None):
+    """The same re-stride with one equal-size all-gather instead of the uneven all-to-all: every rank receives the whole
+    layer (G times the bytes) and cuts its chunks out.  Bit-identical result; the simplest possible collective."""
+    import torch
+    if world == 1:
+        return piece
+    cw = (piece.numel() // elem_words // folding) * elem_words
+    full = _all_gather_cat(piece, world, group)
+    return torch.cat([full[(j * world + rank) * cw:(j * world + rank + 1) * cw] for j in range(folding)])
+
+
 def fri_restride(piece, elem_words, world, rank, folding, group=None):
     """piece: this rank's contiguous length/G elements (torch uint64, flat).  Returns the rank's chunk-major buffer
     [folding][rc/G] (flat): element (j, i) = e[i0 + i + j*rc] with i0 = rank * rc/G.  Received blocks arrive ordered by
