@@ -90,7 +90,7 @@ def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
     column is non-trivial), and the verifier's consistency equation at a random out-of-domain point z
     (verifier/src/evaluator.rs:16-89): constraints evaluated on the OOD frame == sum_i z^(i n) H_i(z)."""
     ctx, prover, fields, air_mod, crypto = wf
-    from test_oracle_deep import Ext
+    from verifier_util import Ext, ood_constraint_equation_holds
     from winterfell_amd.math import fft
     n, blowup = 1 << log_n, 8
     fld, ofld, trace, air = _setup(oracle, fields, air_mod, fname, air_id, n, blowup)
@@ -102,7 +102,7 @@ def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
     commitment, cpoly = prover.build_constraint_commitment(crypto.Blake3_256, out, ncols, domain, ext_degree=D, field=fld, ctx=ctx)
     assert cpoly.num_columns() == ncols and commitment.evaluations.num_rows() == n * blowup
     # ---- verifier-side check at z
-    E = Ext(ofld, D)
+    E = Ext(ofld, D, fld.new(1))
     rng = np.random.default_rng(11)
     z = [int(rng.integers(1, 2**62)) % fld.M for _ in range(D)]
     zw = fld.pack(z)
@@ -111,42 +111,16 @@ def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
     qcur, _ = prover.composition_poly_ood_frame(cpoly, zw, D)
     one = fld.new(1)
     g = fld.new(fld.get_root_of_unity(log_n))
-
-    def zpow(e):
-        r, b = E.lift(one), z
-        while e:
-            if e & 1:
-                r = E.mul(r, b)
-            b = E.mul(b, b)
-            e >>= 1
-        return r
-    zn = zpow(n)
+    zn = E.pow(z, n)
     H, zi = [0] * D, E.lift(one)
     for i in range(ncols):                                  # sum_i z^(i n) H_i(z), verifier/src/lib.rs ood check
         H = E.add(H, E.mul(zi, fld.unpack(qcur[i])))
         zi = E.mul(zi, zn)
     per = np.zeros(0, dtype=np.uint64)
     if air_id == 1:
-        per = ofld.evaluate_columns_at(ofld.air_periodic_polys(1), 9, fld.pack(zpow(n // 16)), D, 1).reshape(-1)
+        per = ofld.evaluate_columns_at(ofld.air_periodic_polys(1), 9, fld.pack(E.pow(z, n // 16)), D, 1).reshape(-1)
     tev = fld.unpack(ofld.air_evaluate_transition(air_id, D, cur.reshape(-1), nxt.reshape(-1), per))
-    T = [0] * D
-    for k in range(air.num_transition_constraints()):
-        T = E.add(T, E.mul(fld.unpack(cc.transition[k]), tev[k * D:(k + 1) * D]))
-    num_t, den_t = E.sub(zn, E.lift(one)), E.sub(z, E.lift(ofld.exp(g, n - 1)))
-    groups, curl = {}, fld.unpack(cur.reshape(-1))
-    for a, ccb in zip(ev.assertions, cc.boundary):
-        evl = E.sub(curl[a.column * D:(a.column + 1) * D], E.lift(a.value))
-        groups[a.first_step] = E.add(groups.get(a.first_step, [0] * D), E.mul(fld.unpack(ccb), evl))
-    divs = {s: E.sub(z, E.lift(ofld.exp(g, s))) for s in groups}
-    prod_all = E.lift(one)
-    for d in divs.values():
-        prod_all = E.mul(prod_all, d)
-    lhs = E.mul(E.mul(H, num_t), prod_all)
-    rhs = E.mul(E.mul(T, den_t), prod_all)
-    for s, B in groups.items():
-        other = E.lift(one)
-        for s2, d in divs.items():
-            if s2 != s:
-                other = E.mul(other, d)
-        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
-    assert lhs == rhs
+    nt = air.num_transition_constraints()
+    assert ood_constraint_equation_holds(E, one, g, n, z, H, [tev[k * D:(k + 1) * D] for k in range(nt)],
+                                         [fld.unpack(c) for c in cc.transition], [fld.unpack(r) for r in cur],
+                                         [(a.column, a.first_step, a.value) for a in ev.assertions], [fld.unpack(c) for c in cc.boundary])

@@ -58,25 +58,7 @@ class FriChannel:
         return a
 
 
-class ExtOps:
-    """degree-D extension arithmetic on internal-form python ints through the oracle's scalar field functions"""
-
-    def __init__(self, ofld, D, one):
-        self.o, self.D, self.one = ofld, D, one
-
-    def add(self, a, b): return [self.o.add(x, y) for x, y in zip(a, b)]
-    def sub(self, a, b): return [self.o.sub(x, y) for x, y in zip(a, b)]
-    def mul(self, a, b): return self.o.ext_mul(self.D, a, b)
-    def lift(self, v): return [v] + [0] * (self.D - 1)
-
-    def pow(self, a, e):
-        r = self.lift(self.one)
-        while e:
-            if e & 1:
-                r = self.mul(r, a)
-            a = self.mul(a, a)
-            e >>= 1
-        return r
+from verifier_util import Ext as ExtOps, ood_constraint_equation_holds  # noqa: E402
 
 
 @pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 2), ("fib_small", "f64", "Rp64_256", 1 << 8, 1),
@@ -161,26 +143,10 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
     if air_id == 1:
         per = ofld.evaluate_columns_at(ofld.air_periodic_polys(1), 9, fld.pack(E.pow(zi, n // 16)), D, 1).reshape(-1)
     tev = fld.unpack(ofld.air_evaluate_transition(air_id, D, ood_cur.reshape(-1), ood_next.reshape(-1), per))
-    T = [0] * D
-    for k in range(nt):
-        T = E.add(T, E.mul(fld.unpack(cc.transition[k]), tev[k * D:(k + 1) * D]))
-    num_t, den_t = E.sub(zn, E.lift(one)), E.sub(zi, E.lift(ofld.exp(g, n - 1)))
-    groups, curl = {}, fld.unpack(ood_cur.reshape(-1))
-    for a, ccb in zip(evaluator.assertions, cc.boundary):
-        ev = E.sub(curl[a.column * D:(a.column + 1) * D], E.lift(a.value))
-        groups[a.first_step] = E.add(groups.get(a.first_step, [0] * D), E.mul(fld.unpack(ccb), ev))
-    divs = {s: E.sub(zi, E.lift(ofld.exp(g, s))) for s in groups}
-    prod_all = E.lift(one)
-    for d in divs.values():
-        prod_all = E.mul(prod_all, d)
-    rhs = E.mul(E.mul(T, den_t), prod_all)
-    for s, B in groups.items():
-        other = E.lift(one)
-        for s2, d in divs.items():
-            if s2 != s:
-                other = E.mul(other, d)
-        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
-    assert E.mul(E.mul(H, num_t), prod_all) == rhs
+    assert ood_constraint_equation_holds(E, one, g, n, zi, H, [tev[k * D:(k + 1) * D] for k in range(nt)],
+                                         [fld.unpack(c) for c in cc.transition], [fld.unpack(r) for r in ood_cur],
+                                         [(a.column, a.first_step, a.value) for a in evaluator.assertions],
+                                         [fld.unpack(c) for c in cc.boundary])
     # (c) DEEP composition at every query position from the opened rows (verifier/src/composer.rs)
     g_lde = fld.new(fld.get_root_of_unity(N.bit_length() - 1))
     zg = E.mul(zi, E.lift(g))

@@ -8,7 +8,7 @@ plus the structural facts the prover asserts: the combined evaluations interpola
 import numpy as np
 import pytest
 
-from test_oracle_deep import Ext
+from verifier_util import Ext, ood_constraint_equation_holds
 
 
 def _setup(oracle, fname):
@@ -83,35 +83,11 @@ def test_prover_evaluation_matches_verifier_formula(oracle, fname, air, n, D):
             zc = E.mul(zc, z)
         per = fld.evaluate_columns_at(fld.air_periodic_polys(c["air"]), c["npc"], fld.pack(zc), D, 1).reshape(-1)
     tev = fld.unpack(fld.air_evaluate_transition(c["air"], D, cur.reshape(-1), nxt.reshape(-1), per))
-    T = [0] * D
-    for k in range(c["nt"]):
-        T = E.add(T, E.mul(c["cc_t"][k], tev[k * D:(k + 1) * D]))
-    zn = E.lift(new(1))
-    for _ in range(n):
-        zn = E.mul(zn, z)
-    num_t = E.sub(zn, E.lift(new(1)))                                         # x^n - 1
-    den_t = E.sub(z, E.lift(fld.exp(g, n - 1)))                               # x - g^(n-1)
-    groups = {}
+    E.one = new(1)
     curl = fld.unpack(cur.reshape(-1))
-    for (col, step, val), cc in zip(c["assertions"], c["cc_b"]):
-        ev = E.sub(curl[col * D:(col + 1) * D], E.lift(val))
-        groups.setdefault(step, [0] * D)
-        groups[step] = E.add(groups[step], E.mul(cc, ev))
-    divs = {step: E.sub(z, E.lift(fld.exp(g, step))) for step in groups}
     H = E.horner([fld.unpack(row) for row in co], z)
-    # H * num_t * prod(divs) == T * den_t * prod(divs) + sum_g B_g * num_t * prod(divs except g)
-    prod_all = E.lift(new(1))
-    for d in divs.values():
-        prod_all = E.mul(prod_all, d)
-    lhs = E.mul(E.mul(H, num_t), prod_all)
-    rhs = E.mul(E.mul(T, den_t), prod_all)
-    for step, B in groups.items():
-        other = E.lift(new(1))
-        for s2, d in divs.items():
-            if s2 != step:
-                other = E.mul(other, d)
-        rhs = E.add(rhs, E.mul(E.mul(B, num_t), other))
-    assert lhs == rhs
+    assert ood_constraint_equation_holds(E, new(1), g, n, z, H, [tev[k * D:(k + 1) * D] for k in range(c["nt"])], c["cc_t"],
+                                         [curl[k * D:(k + 1) * D] for k in range(c["width"])], c["assertions"], c["cc_b"])
 
 
 @pytest.mark.parametrize("fname,air,n", [("f64", 0, 32), ("f128", 1, 32)])

@@ -11,29 +11,7 @@ def _fields(oracle):
     return {"f64": (oracle.f64t, (1, 2, 3)), "f128": (oracle.f128, (1, 2)), "f62": (oracle.f62, (1, 2, 3))}
 
 
-class Ext:
-    """Degree-D extension elements as lists of internal-form python ints, on top of the oracle's scalar ops."""
-
-    def __init__(self, fld, D):
-        self.f, self.D = fld, D
-
-    def add(self, a, b):
-        return [self.f.add(x, y) for x, y in zip(a, b)]
-
-    def sub(self, a, b):
-        return [self.f.sub(x, y) for x, y in zip(a, b)]
-
-    def mul(self, a, b):
-        return self.f.ext_mul(self.D, a, b)
-
-    def lift(self, v):
-        return [v] + [0] * (self.D - 1)
-
-    def horner(self, coeffs, x):
-        acc = [0] * self.D
-        for c in reversed(coeffs):
-            acc = self.add(self.mul(acc, x), c)
-        return acc
+from verifier_util import Ext  # noqa: E402
 
 
 def make_case(fld, D, n, c_main, c_aux, c_q, seed):
