@@ -55,6 +55,7 @@ struct PassParams {
     uint32_t post_log_lo;
     uint32_t has_post_const;
     T post_const;
+    uint32_t scale_in_w256;   // last pass of an inverse transform: w256 already carries the 1/n (applied for k_a = 0 too)
 };
 
 #ifndef NTT_WAVES_PER_EU
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
             for (int i = 0; i < A; i++) {
                 const int ka = brev(i, LOG_A);
                 T val = x[i];
-                if (ka != 0) val = F::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
+                if (ka != 0 || (LAST && p.scale_in_w256)) val = F::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
                 if (!LAST) lds[ka * ROW_NL + b1 * TC + t1] = val;
                 else lds[(ka * TC + t1) * ROW_L + b1] = val;
             }
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
             uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
             if (p.inverse) k = (n - k) & (n - 1);
             if (p.post_lo != nullptr) val = F::mul(val, series_at32<F>(p.post_lo, p.post_hi, p.post_log_lo, (uint32_t)k));
-            else if (p.has_post_const) val = F::mul(val, p.post_const);
+            else if (p.has_post_const && !p.scale_in_w256) val = F::mul(val, p.post_const);
             dst[k * p.dst_es] = val;
         }
     };
@@ -329,6 +330,16 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             p.dst_es = 1;
         }
         const uint32_t r = p.log_r[q];
+        // a constant output scale (the 1/n of interpolate_poly) rides on the last pass's intra-pass twiddles when that
+        // pass has any (B > 1): 16 multiplications per lane instead of 15 + 16
+        p.scale_in_w256 = 0;
+        p.w256 = (const T *)w256;
+        if (last && job.has_post_const && log_b_for(r) > 0) {
+            void *ws;
+            WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
+            p.w256 = (const T *)ws;
+            p.scale_in_w256 = 1;
+        }
         const uint32_t Tc = 256u >> log_b_for(r);
         const uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
         const uint64_t blocks = (total_cols + Tc - 1) / Tc;

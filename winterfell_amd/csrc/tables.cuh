@@ -86,6 +86,30 @@ static int wf_get_small_tables(wf_ctx *ctx, void **w256, void **w16) {
     return WF_OK;
 }
 
+// c * omega_256^e, e < 256 (c canonical)
+template <class HF>
+static int wf_get_scaled_w256(wf_ctx *ctx, typename HF::T c, void **out) {
+    typedef typename HF::T T;
+    uint64_t c0, c1;
+    split128(c, c0, c1);
+    const auto key = std::make_tuple((int)HF::Dev::ID, c0, c1);
+    auto it = ctx->w256_scaled.find(key);
+    if (it == ctx->w256_scaled.end()) {
+        std::vector<T> h(256);
+        const T w = HF::root_of_unity(8);
+        T cur = c;
+        for (int i = 0; i < 256; i++) {
+            h[i] = HF::to_internal(cur);
+            cur = HF::mulmod(cur, w);
+        }
+        void *p;
+        WF_TRY(wf_upload(ctx, h, &p));
+        it = ctx->w256_scaled.emplace(key, p).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
 // LDE pre-scale tables: for coset u (rows u + b*m of the LDE), series (offset * g^u)^j, j < n, g = omega_{n*b}
 template <class HF>
 static int wf_get_lde_tables(wf_ctx *ctx, typename HF::T offset_canon, uint32_t log_n, uint32_t log_b, wf_ctx::LdeTables *out,

@@ -47,6 +47,8 @@ struct wf_ctx {
     std::map<SeriesKey, SeriesTable> series;
     // per field: omega_256^e (256 entries, intra-pass twiddles) and omega_16^j (8 entries, register DFT constants)
     std::map<int, void *> w256, w16;
+    // omega_256^e * c for a constant c (the 1/n of an inverse transform folded into the last pass's twiddles)
+    std::map<std::tuple<int, uint64_t, uint64_t>, void *> w256_scaled;
     // LDE pre-scale tables: key (field, offset (128 bit), log_n, log_blowup) -> contiguous [u][lo] / [u][hi]
     struct LdeTables {
         void *d_lo = nullptr, *d_hi = nullptr;
