@@ -24,6 +24,8 @@
 #pragma once
 #include <string.h>
 
+#include <type_traits>
+
 #include "dft_regs.cuh"
 #include "tables.cuh"
 #include "wf_internal.h"
@@ -198,9 +200,32 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
         }
     };
 
-    if (B == 1) {
+    // Non-last passes: the inter-pass twiddles of one lane's outputs k' = k0 + STEP * i form a geometric progression
+    // omega^((k0 + STEP i) * rem * mult) = base * step^i, so two table look-ups (base, step) and a multiplication chain
+    // replace a two-level look-up per output: 2 + (CNT - 1) + CNT multiplications instead of 2 (CNT - 1), but 4 loads
+    // instead of 2 CNT and none of the per-output index arithmetic.
+    auto emit_progression = [&](auto &vals, uint32_t k0, uint32_t step_k, auto log_cnt_tag) {
+        constexpr int LOG_CNT = decltype(log_cnt_tag)::value;
+        constexpr int CNT = 1 << LOG_CNT;
+        const uint32_t r32 = (uint32_t)rem;
+        T cur = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (k0 * r32) << log_mult);
+        const T stp = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (step_k * r32) << log_mult);
 #pragma unroll
-        for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
+        for (int ip = 0; ip < CNT; ip++) {
+            const int i = brev(ip, LOG_CNT);                 // register holding output digit ip
+            const uint32_t kp = k0 + step_k * (uint32_t)ip;
+            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(vals[i], cur);
+            if (ip + 1 < CNT) cur = F::mul(cur, stp);
+        }
+    };
+
+    if constexpr (B == 1) {
+        if constexpr (!LAST) {
+            emit_progression(x, 0u, 1u, std::integral_constant<int, LOG_A>{});
+        } else {
+#pragma unroll
+            for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
+        }
     } else {
 #pragma unroll
         for (int g = 0; g < G; g++) {
@@ -212,8 +237,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 else y[bb] = lds[(ka * TC + t2) * ROW_L + bb];
             }
             dft_dif<F, LOG_B>(y, p.w16);
+            if constexpr (!LAST) {
+                emit_progression(y, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
+            } else {
 #pragma unroll
-            for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+                for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+            }
         }
     }
 }
