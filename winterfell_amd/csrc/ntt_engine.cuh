@@ -145,10 +145,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 uint32_t uq, u;
                 divmod_uniform((uint32_t)v, p.pre_mod, uq, u);
                 const T *plo = p.pre_lo + u * p.pre_lo_stride, *phi = p.pre_hi + u * p.pre_hi_stride;
+                // the lane's A inputs sit at j0 + a * (B << log_s): their scale factors base^j are a geometric progression
+                // (the tables hold base^j with no extra factor), so two look-ups and a chain replace A look-ups
+                T cur = series_at32<F>(plo, phi, p.pre_log_lo, (uint32_t)(base + ((uint64_t)b1 << log_s)));
+                const T stp = series_at32<F>(plo, phi, p.pre_log_lo, (uint32_t)B << log_s);
 #pragma unroll
                 for (int a = 0; a < A; a++) {
-                    const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                    x[a] = F::mul(x[a], series_at<F>(plo, phi, p.pre_log_lo, j));
+                    x[a] = F::mul(x[a], cur);
+                    if (a + 1 < A) cur = F::mul(cur, stp);
                 }
             }
         } else {
