@@ -58,6 +58,9 @@ struct PassParams {
     uint32_t has_post_const;
     T post_const;
     uint32_t scale_in_w256;   // last pass of an inverse transform: w256 already carries the 1/n (applied for k_a = 0 too)
+    // row-major output mode of the last pass (NttJob::rowmajor)
+    uint32_t rowmajor, rm_log_b, rm_log_i, rm_base_cols;
+    uint64_t rm_row_width;
 };
 
 #ifndef NTT_WAVES_PER_EU
@@ -99,7 +102,29 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     const uint32_t L = p.log_n;
     const uint64_t n = 1ull << L;
     const uint64_t ncols = n >> LOG_R;                     // columns per vector
-    const uint64_t total_cols = ncols * (uint64_t)p.nvec;  // joint (vector, column) space
+    const bool RM = LAST && p.rowmajor;
+    const uint32_t log_ncols = L - LOG_R;                  // ncols is a power of two
+    // joint (vector, column) space; in row-major mode: [column group][coset u][column c][column-in-group] (last fastest)
+    const uint32_t rm_groups = RM ? (p.rm_base_cols + (1u << p.rm_log_i) - 1) >> p.rm_log_i : 0;
+    const uint64_t total_cols = RM ? ((uint64_t)rm_groups << (p.rm_log_b + log_ncols + p.rm_log_i)) : ncols * (uint64_t)p.nvec;
+    // (vector v, column c) of joint index cc; in row-major mode also the base column bc and the coset u, and whether the
+    // lane carries a real column (lanes past base_cols in the last group only write padding zeros)
+    auto decompose = [&](uint64_t cc, uint64_t &v, uint64_t &c, uint32_t &bc, uint32_t &u) -> bool {
+        if (!RM) {
+            v = cc >> log_ncols;
+            c = cc & (ncols - 1);
+            bc = u = 0;
+            return true;
+        }
+        const uint32_t ci = (uint32_t)cc & ((1u << p.rm_log_i) - 1);
+        const uint64_t r1 = cc >> p.rm_log_i;
+        c = r1 & (ncols - 1);
+        const uint64_t r2 = r1 >> log_ncols;
+        u = (uint32_t)r2 & ((1u << p.rm_log_b) - 1);
+        bc = ((uint32_t)(r2 >> p.rm_log_b) << p.rm_log_i) + ci;
+        v = ((uint64_t)bc << p.rm_log_b) + u;
+        return bc < p.rm_base_cols;
+    };
     const uint64_t cc0 = (uint64_t)blockIdx.x * TC;
 
     // log2 of this digit's stride S_p
@@ -113,10 +138,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     T x[A];
     {
         const uint64_t cc = cc0 + t1;
-        const bool active = cc < total_cols;
-        const uint32_t log_ncols = L - LOG_R;                // ncols is a power of two
-        const uint64_t v = active ? cc >> log_ncols : 0;
-        const uint64_t c = active ? cc & (ncols - 1) : 0;
+        uint64_t v = 0, c = 0;
+        uint32_t bc1, u1;
+        const bool active = cc < total_cols && decompose(cc, v, c, bc1, u1);
         uint64_t base;
         if (!LAST) {
             const uint64_t rem = c & ((1ull << log_s) - 1);
@@ -180,8 +204,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     const int q2 = (B > 1) ? tid / TC : 0;
     const uint64_t cc = cc0 + t2;
     if (cc >= total_cols) return;
-    const uint64_t v = cc >> (L - LOG_R);
-    const uint64_t c = cc & (ncols - 1);
+    uint64_t v, c;
+    uint32_t bc2, u2;
+    const bool real_col = decompose(cc, v, c, bc2, u2);
     uint32_t dq, dr;
     divmod_uniform((uint32_t)v, p.dst_inner, dq, dr);
     T *dst = p.dst + (uint64_t)dq * p.dst_vec_stride + (uint64_t)dr * p.dst_inner_stride;
@@ -195,6 +220,13 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 val = F::mul(val, series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, e));
             }
             dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val;
+        } else if (RM) {
+            // LDE row u + b * m, column bc; the last group's lanes also zero the padding columns of that row
+            T *row = p.dst + (u2 + ((c + ncols * (uint64_t)kp) << p.rm_log_b)) * p.rm_row_width;
+            if (real_col) row[bc2] = val;
+            if ((bc2 >> p.rm_log_i) + 1 == rm_groups) {
+                for (uint64_t pc = p.rm_base_cols + (bc2 & ((1u << p.rm_log_i) - 1)); pc < p.rm_row_width; pc += 1u << p.rm_log_i) row[pc] = F::zero();
+            }
         } else {
             uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
             if (p.inverse) k = (n - k) & (n - 1);
@@ -323,6 +355,12 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     p.post_log_lo = job.post_log_lo;
     p.has_post_const = job.has_post_const ? 1 : 0;
     memcpy((void *)&p.post_const, (const void *)job.post_const, sizeof(T));
+    p.rowmajor = 0;
+    p.rm_log_b = job.rm_log_b;
+    p.rm_log_i = job.rm_log_i;
+    p.rm_base_cols = job.rm_base_cols;
+    p.rm_row_width = job.rm_row_width;
+    if (job.rowmajor && (job.nvec != (job.rm_base_cols << job.rm_log_b) || job.rm_log_i > 3)) return WF_ERR_INVALID_ARG;
 
     const uint64_t n = 1ull << L;
     T *tmp = nullptr;
@@ -374,7 +412,12 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             p.scale_in_w256 = 1;
         }
         const uint32_t Tc = 256u >> log_b_for(r);
-        const uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
+        uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
+        p.rowmajor = (last && job.rowmajor) ? 1 : 0;
+        if (p.rowmajor) {
+            const uint64_t groups = (job.rm_base_cols + (1u << job.rm_log_i) - 1) >> job.rm_log_i;
+            total_cols = (groups << (job.rm_log_b + job.rm_log_i)) * (n >> r);
+        }
         const uint64_t blocks = (total_cols + Tc - 1) / Tc;
         if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
         auto k = kernel_for<F>(r, last);

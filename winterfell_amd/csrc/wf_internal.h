@@ -110,6 +110,13 @@ struct NttJob {
     uint32_t post_log_lo = 0;
     bool has_post_const = false;
     uint64_t post_const[2] = {0, 0}; // internal representation, little-endian words
+    // Row-major output (the LDE of RowMatrix::evaluate_polys_over): output vector v = bc * 2^rm_log_b + u is the coset u of
+    // base column bc; element m of it goes to dst[(u + (m << rm_log_b)) * rm_row_width + bc].  The last pass then tiles
+    // over groups of 2^rm_log_i columns (fastest) so that a row's columns are stored together, and the lanes of the last
+    // group also zero the padding columns base_cols .. rm_row_width.  nvec must be rm_base_cols << rm_log_b.
+    bool rowmajor = false;
+    uint32_t rm_log_b = 0, rm_log_i = 0, rm_base_cols = 0;
+    uint64_t rm_row_width = 0;
 };
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field
 int wf_ntt_run_f64(wf_ctx *ctx, const NttJob &job);
