@@ -125,6 +125,26 @@ def main():
             sharded = {"sharded_lde_commit_ms_2^20x%d_b8_blake3" % (4 * world): float(tt.item())}
         except Exception as e:  # never let the optional leg break the headline measurement
             sharded = {"sharded_lde_commit_error": repr(e)[:200]}
+        # row-strided sharding of ONE 2^20 x 4 trace (replicated input): bit-identical to the default single-device
+        # commitment; rank k evaluates and hashes the LDE rows r = k (mod N), leaves cross xGMI (equal-size all-to-all)
+        try:
+            if world <= 8:
+                full = prover.ColMatrix(ctx.to_device(np.random.default_rng(11).integers(0, fields.M, (4, 1 << 20), dtype=np.uint64)))
+                sb = parallel.HipStridedBackend(crypto.Blake3_256, fields.f64, ctx)
+                srun = lambda: parallel.strided_commit(sb, full, 1 << 20, 8, 7, fields.f64)
+                srun()
+                ts = []
+                for _ in range(5):
+                    barrier()
+                    t1 = time.perf_counter()
+                    srun()
+                    barrier()
+                    ts.append((time.perf_counter() - t1) * 1e3)
+                tt = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                sharded["strided_lde_commit_ms_2^20x4_b8_blake3"] = float(tt.item())
+        except Exception as e:
+            sharded["strided_lde_commit_error"] = repr(e)[:200]
         # FRI commit phase of a 2^24-point quadratic-extension LDE (configs[4]) sharded by row ranges: all-to-all re-stride
         # + sub-root all-gather per layer, tail layers collapsed onto every rank
         try:

@@ -262,3 +262,28 @@ def test_constraint_commitment_vs_oracle(wf, oracle, D, num_cols, ce_blowup):
     assert np.array_equal(rows, o_lde[[5, 100], : num_cols * D])
     with pytest.raises(AssertionError, match="trace length must be smaller"):
         prover.CompositionPoly.new(comp_trace[: n * D], domain, 1, ext_degree=D)
+
+
+@pytest.mark.parametrize("world,hname,fname,c,log_n,blowup", [(2, "Blake3_256", "f64", 5, 8, 8), (8, "Blake3_256", "f64", 12, 7, 8),
+                                                                (4, "Rp64_256", "f64", 3, 6, 4), (8, "Blake3_256", "f128", 4, 6, 8)])
+def test_strided_sharding_emulation_equals_default_commitment(wf, oracle, world, hname, fname, c, log_n, blowup):
+    """SURVEY 8e Alternative B on one device: G logical ranks each run interpolate + coset LDE (blowup b/G, offset s*g^k) +
+    plain row hashes through the kernels; after the leaf exchange the tree is the default unpartitioned commitment."""
+    ctx, crypto, prover, fields = wf[0], wf[1], wf[2], wf[3]
+    from winterfell_amd import parallel
+    fld, ofld = {"f64": (fields.f64, oracle.f64t), "f128": (fields.f128, oracle.f128)}[fname]
+    hasher = getattr(crypto, hname)
+    hid = 0 if hname == "Blake3_256" else 1
+    n = 1 << log_n
+    rng = np.random.default_rng(world + c)
+    vals = [int(a) * int(b) % fld.M for a, b in zip(rng.integers(1, 2**62, c * n), rng.integers(1, 2**62, c * n))]
+    trace = fld.pack([fld.new(v) for v in vals]).reshape(c, -1)
+    res = parallel.emulated_strided_commit(parallel.HipStridedBackend(hasher, fld, ctx), prover.ColMatrix(trace, 1, ctx, fld), n, blowup,
+                                           fld.GENERATOR, fld, world)
+    o = ofld.build_trace_commitment(hid, trace, blowup, fld.new(fld.GENERATOR))
+    N = n * blowup
+    assert np.array_equal(ctx.to_host(res["root"]), o[3][1])
+    for k in range(world):
+        assert np.array_equal(ctx.to_host(res["shards"][k][1].data), o[1][k::world])
+    full = parallel.assemble_nodes(world, N, [ctx.to_host(nd) for _, nd in res["per_rank"]], ctx.to_host(res["top"]))
+    assert np.array_equal(full, o[3])

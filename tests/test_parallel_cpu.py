@@ -249,3 +249,55 @@ def test_fri_restride_plan_routes_every_chunk(world, N, length):
         want = np.concatenate([e[j * rc + g * chunk:j * rc + (g + 1) * chunk] for j in range(N)])
         assert np.array_equal(got, want)
         assert sum(plans[g][2]) == N * chunk
+
+
+# ---- row-strided sharding: bit-exact with the default (unpartitioned) commitment -------------------------------------
+class _OracleStridedBackend(_OracleBackend):
+    def local_commit(self, trace, sub_blowup, sub_offset_int):
+        import torch
+        polys, lde, leaves, _ = self.o.build_trace_commitment(self.h, trace, sub_blowup, self.o.f64_new(sub_offset_int))
+        return polys, lde, torch.from_numpy(leaves.copy())
+
+
+def _strided_worker(rank, world, port, hasher_id, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch.distributed as dist
+    from conftest import splitmix64
+    import oracle
+    from winterfell_amd import parallel
+    from winterfell_amd.math import fields
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    n, c, blowup = 64, 5, 8
+    trace = oracle.f64_from_int(splitmix64(99, n * c)).reshape(c, n)
+    res = parallel.strided_commit(_OracleStridedBackend(hasher_id), trace, n, blowup, 7, fields.f64)
+    np.savez(os.path.join(out_dir, "strided%d.npz" % rank), nodes=res["nodes"].numpy(), top=res["top"].numpy(), root=res["root"].numpy(),
+             leaves=res["leaves"].numpy(), lde=res["lde"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,hasher_id", [(2, 0), (4, 1), (8, 0)])
+def test_strided_commit_equals_default_single_process(oracle, tmp_path, world, hasher_id):
+    """SURVEY 8e Alternative B: rank k evaluates and hashes the LDE rows r = k (mod G) (a coset LDE with blowup b/G and
+    offset s*g^k), leaves are exchanged, and the tree equals the DEFAULT num_partitions = 1 commitment node for node."""
+    import torch.multiprocessing as mp
+    from conftest import splitmix64
+    from winterfell_amd import parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_strided_worker, args=(world, port, hasher_id, str(tmp_path)), nprocs=world, join=True)
+    n, c, blowup = 64, 5, 8
+    N = n * blowup
+    trace = oracle.f64_from_int(splitmix64(99, n * c)).reshape(c, n)
+    _, lde, leaves, nodes = oracle.build_trace_commitment(hasher_id, trace, blowup, oracle.f64_new(7))
+    got = [np.load(os.path.join(str(tmp_path), "strided%d.npz" % r)) for r in range(world)]
+    per = N // world
+    for r in range(world):
+        assert np.array_equal(got[r]["root"], nodes[1])
+        assert np.array_equal(got[r]["leaves"], leaves[r * per:(r + 1) * per])
+        assert np.array_equal(got[r]["lde"], lde[r::world])                       # rank r holds rows r, r + G, r + 2G, ...
+    full = parallel.assemble_nodes(world, N, [g["nodes"] for g in got], got[0]["top"])
+    assert np.array_equal(full, nodes)

@@ -403,3 +403,82 @@ def emulated_sharded_fri(backends_factory, options, channel_factory, evaluations
         tail, rem = backend.finish_unsharded(_TailOptions(options, total_layers - done), channels[r], vector.clone())
         results[r]["tail"], results[r]["remainder"] = tail, rem
     return results, channels
+
+
+# ==== Row-strided sharding of the trace commitment ("Alternative B") ==============================
+#
+# Bit-identical to the DEFAULT single-device commitment (num_partitions = 1), unlike the column/partition sharding above:
+# rank k owns the LDE rows r = k (mod G).  Those rows are the evaluations over the coset (offset * g^k) * <g^G> of size
+# N / G, i.e. exactly `RowMatrix::evaluate_polys_over(polys, blowup / G, offset * g^k)` — no new kernel.  Every rank holds
+# the (replicated) trace, interpolates all columns (1 / (1 + b/G) of its work is redundant), evaluates and hashes ITS rows
+# with the plain unpartitioned hash_elements, then
+#   all-to-all of leaves: the leaves of rows in [g*N/G, (g+1)*N/G) go to rank g — a CONTIGUOUS block of every sender's local
+#                         leaves because r = k + G*t is monotone in t; the receiver interleaves them (row = k + G*t')
+#   subtree per rank, all-gather of the G sub-roots, top log2(G) levels on every rank (as in sharded_commit).
+# Requires G <= blowup (G a power of two).  Queries: LDE row p lives on rank p % G at local row p // G.
+
+def strided_commit(backend, trace, domain_size_n, blowup, offset_int, field, world=None, rank=None, group=None):
+    """trace: the full column-major trace (every rank passes the same).  `offset_int`: the domain offset as a CANONICAL
+    integer.  Returns dict(polys, lde (local rows r = rank + G*t), local_leaves, leaves (this rank's row range), nodes, top,
+    root)."""
+    import torch
+    import torch.distributed as dist
+    if world is None:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    assert world & (world - 1) == 0 and world <= blowup, "row-strided sharding needs a power-of-two world size <= blowup"
+    N = domain_size_n * blowup
+    g = field.get_root_of_unity(N.bit_length() - 1)
+    sub_offset = offset_int * pow(g, rank, field.M) % field.M
+    polys, lde, local_leaves = backend.local_commit(trace, blowup // world, sub_offset)
+    if world == 1:
+        leaves = local_leaves
+    else:
+        per = N // world // world                               # leaves per (sender, receiver) pair
+        send = local_leaves.contiguous().view(world, per, 32)
+        recv = torch.empty_like(send)
+        try:
+            dist.all_to_all_single(recv.view(-1), send.view(-1), group=group)
+        except (RuntimeError, NotImplementedError):
+            bufs = [torch.empty_like(local_leaves) for _ in range(world)]
+            dist.all_gather(bufs, local_leaves.contiguous(), group=group)
+            recv = torch.stack([b.view(world, per, 32)[rank] for b in bufs])
+        leaves = recv.permute(1, 0, 2).contiguous().view(N // world, 32)    # row = k + G * t'
+    nodes = backend.merkle_nodes(leaves)
+    sub_root = nodes[1] if leaves.shape[0] > 1 else nodes[0]
+    if world == 1:
+        return dict(polys=polys, lde=lde, local_leaves=local_leaves, leaves=leaves, nodes=nodes, top=None, root=sub_root)
+    roots = gather_subroots(sub_root, group)
+    top = backend.merkle_nodes(roots)
+    return dict(polys=polys, lde=lde, local_leaves=local_leaves, leaves=leaves, nodes=nodes, top=top, root=top[1], rank=rank, world=world)
+
+
+class HipStridedBackend(HipBackend):
+    """local_commit on the GPU: interpolate all columns, LDE of this rank's row stride, plain row hashes."""
+
+    def __init__(self, hasher, field, ctx=None):
+        super().__init__(hasher, ctx)
+        self.field = field
+
+    def local_commit(self, trace, sub_blowup, sub_offset_int):
+        from .prover.matrix import RowMatrix
+        polys = trace.interpolate_columns()
+        lde = RowMatrix.evaluate_polys_over(polys, sub_blowup, self.field.new(sub_offset_int))
+        return polys, lde, lde.hash_rows(self.hasher)
+
+
+def emulated_strided_commit(backend, trace, n, blowup, offset_int, field, world):
+    """G logical ranks on one device, the exchange done by slicing (same index math as strided_commit)."""
+    import torch
+    N = n * blowup
+    g = field.get_root_of_unity(N.bit_length() - 1)
+    locals_ = [backend.local_commit(trace, blowup // world, offset_int * pow(g, k, field.M) % field.M) for k in range(world)]
+    per = N // world // world
+    out = []
+    for r in range(world):
+        recv = torch.stack([locals_[k][2].view(world, per, 32)[r] for k in range(world)])       # [k][t'][32]
+        leaves = recv.permute(1, 0, 2).contiguous().view(N // world, 32)
+        out.append((leaves, backend.merkle_nodes(leaves)))
+    roots = torch.stack([nd[1] if N // world > 1 else nd[0] for _, nd in out])
+    top = backend.merkle_nodes(roots) if world > 1 else None
+    return dict(shards=locals_, per_rank=out, top=top, root=top[1] if world > 1 else roots[0])
