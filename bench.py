@@ -40,11 +40,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
+    # one process per GPU; WF_BENCH_BACKEND=gloo (with fewer devices than ranks) only exists to exercise the N > 1 control
+    # flow on a single-GPU box — the measured configuration is always nccl (= RCCL) with one device per rank
+    backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
+    device_index = local_rank % max(torch.cuda.device_count(), 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    torch.cuda.set_device(local_rank)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend=backend)
+    torch.cuda.set_device(device_index)
+    local_rank = device_index
 
     import winterfell_amd
     from winterfell_amd import crypto, prover
