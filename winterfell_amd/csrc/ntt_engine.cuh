@@ -13,10 +13,13 @@
 //     a thread holds A = 2^LOG_A elements in registers and runs an A-point DFT whose internal twiddles
 //     are powers of omega_16 = 2^12 (shifts, no multiplies; omega_64 = 8 in this field, f64/mod.rs:258-267),
 //   - multiplies by omega_{R_p}^(k_a * b), exchanges through LDS (padded, conflict-free),
-//   - runs the B-point DFT, multiplies by the inter-pass twiddle omega_n^(...) from a two-level table,
+//   - runs the B-point DFT, multiplies by the inter-pass twiddles omega_n^(k' * rem * mult): a lane's 16 outputs
+//     k' = k0 + 16 i form a geometric progression base * step^i, so two look-ups in the two-level table and a
+//     multiplication chain replace sixteen look-ups (the same trick scales the inputs of a coset transform),
 //   - stores.  Passes 1..P-1 store in place (tile rows at the same addresses, coalesced along the
 //     columns); the last pass runs along the contiguous axis and stores digit-reversed so that the
-//     result is in natural order (coalesced along the tile's columns, which are the low output digits).
+//     result is in natural order (coalesced along the tile's columns, which are the low output digits), or, for
+//     the LDE of a wide trace, straight into the row-major matrix (NttJob::rowmajor).
 // The inverse transform is the forward transform with the output index negated (k -> -k mod n) and a
 // 1/n scale, so only forward tables exist.
 //
