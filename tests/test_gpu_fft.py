@@ -142,3 +142,20 @@ def test_full_size_properties(wf, oracle, log_n):
     idx = np.random.default_rng(1).integers(0, n, 2000)
     for k in idx:
         assert es[k] == oracle.f64_add(int(host[k]), int(hb[k]))
+
+
+@pytest.mark.parametrize("log_n", [26, 27])
+def test_beyond_baseline_sizes(wf, oracle, log_n):
+    """Sizes above BASELINE's 2^24 (1 GiB vector at 2^27; four passes at 2^26+): round trip and Horner spot values."""
+    ctx, fft, fields = wf
+    import torch
+    n = 1 << log_n
+    a = np.random.default_rng(log_n).integers(0, P, n, dtype=np.uint64)      # canonical words are valid Montgomery residues
+    da = ctx.to_device(a)
+    ea = fft.evaluate_poly(da.clone())
+    assert torch.equal(fft.interpolate_poly(ea.clone()), da)
+    w = oracle.f64_root_of_unity(log_n)
+    ks = [0, 1, 3 * n // 4 + 11, n - 1]
+    vals = ctx.to_host(ea[torch.tensor(ks, device=ea.device)])
+    for k, v in zip(ks, vals):
+        assert int(v) == oracle.poly_eval(a, oracle.f64_exp(w, k)), k
