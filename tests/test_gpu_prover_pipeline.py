@@ -1,61 +1,14 @@
 """End-to-end composition of the device pieces in the order of Prover::generate_proof (prover/src/lib.rs:275-470) for the two
 example AIRs, driven by a host Fiat-Shamir coin, followed by an independent re-check of what a verifier would check from
 the queried data (verifier/src/lib.rs:139-330): Merkle openings, the out-of-domain constraint equation, DEEP composition at
-every query position, and the FRI fold chain down to the remainder.  The coin below is a python restatement of
-DefaultRandomCoin (crypto/src/random/default.rs) on the library's hashers; the exact transcript serialisation of the
-reference's ProverChannel (context / proof bytes) is out of scope, so this is a consistency test of the pipeline, not a
-byte-level proof comparison."""
+every query position, and the FRI fold chain down to the remainder.  The pipeline itself is the product's
+prover.prove() (coin and channel in winterfell_amd/crypto/random.py, winterfell_amd/prover/channel.py); the exact transcript
+serialisation of the reference's ProverChannel (context / proof bytes) is out of scope, so this is a consistency test of
+the pipeline, not a byte-level proof comparison."""
 import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-
-class Coin:
-    """DefaultRandomCoin: seed = hash_elements(seed elements); reseed = merge(seed, data); next = merge_with_int(seed, ++counter)."""
-
-    def __init__(self, hasher, fld, seed_words):
-        self.h, self.f = hasher, fld
-        self.seed = hasher.hash_elements(np.asarray(seed_words, dtype=np.uint64), field=fld)
-        self.counter = 0
-
-    def reseed(self, digest):
-        self.seed = self.h.merge(np.stack([self.seed, np.asarray(digest, dtype=np.uint8).reshape(32)]))
-        self.counter = 0
-
-    def _next(self):
-        self.counter += 1
-        return self.h.digest_as_bytes(self.h.merge_with_int(self.seed, self.counter))
-
-    def draw(self, D):
-        """draw::<E>: the first ELEMENT_BYTES of next() must decode to canonical base elements (default.rs:185-199)."""
-        f = self.f
-        nb = 8 * f.W
-        for _ in range(1000):
-            b = self._next()
-            vals = [int.from_bytes(b[k * nb:(k + 1) * nb], "little") for k in range(D)]
-            if len(b) >= D * nb and all(v < f.M for v in vals):
-                return f.pack([f.new(v) for v in vals])
-        raise RuntimeError("failed to draw")
-
-    def draw_integers(self, num, domain_size, nonce):
-        self.seed = self.h.merge_with_int(self.seed, nonce)
-        self.counter = 0
-        return [int.from_bytes(self._next()[:8], "little") & (domain_size - 1) for _ in range(num)]
-
-
-class FriChannel:
-    def __init__(self, coin, D):
-        self.coin, self.D, self.commitments, self.alphas = coin, D, [], []
-
-    def commit_fri_layer(self, root):
-        self.commitments.append(np.array(root, copy=True))
-        self.coin.reseed(root)
-
-    def draw_fri_alpha(self):
-        a = self.coin.draw(self.D)
-        self.alphas.append(a)
-        return a
 
 
 from verifier_util import Ext as ExtOps, ood_constraint_equation_holds  # noqa: E402
@@ -87,48 +40,56 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
         air = wair.RescueAir(n, [t0[0], t1[0]], [t0[n - 1], t1[n - 1]], blowup)
         pub = [t0[0], t1[0], t0[n - 1], t1[n - 1]]
         air_id = 1
-    coin = Coin(hasher, fld, fld.pack(pub))
     domain = prover.StarkDomain(n, blowup, field=fld)
     N = n * blowup
-    # ---- 2. commit to the main trace (lib.rs:305-306)
-    trace_lde, trace_polys = prover.DefaultTraceLde.new(hasher, prover.ColMatrix(trace, 1, ctx, fld), domain)
-    coin.reseed(trace_lde.get_main_trace_commitment())
-    # ---- 3. constraint composition coefficients, evaluation, commitment (lib.rs:353-371)
-    nt, na = air.num_transition_constraints(), air.num_assertions()
-    cc = prover.ConstraintCompositionCoefficients(np.stack([coin.draw(D) for _ in range(nt)]), np.stack([coin.draw(D) for _ in range(na)]))
-    evaluator = prover.DefaultConstraintEvaluator(air, cc, D)
-    comp_trace = evaluator.evaluate(trace_lde, domain)
-    ncols = air.num_constraint_composition_columns()
-    constraint_com, comp_poly = prover.build_constraint_commitment(hasher, comp_trace, ncols, domain, ext_degree=D, field=fld, ctx=ctx)
-    coin.reseed(constraint_com.commitment())
-    # ---- 4. OOD point, frames, DEEP composition (lib.rs:373-421)
-    z = coin.draw(D)
-    table = prover.TracePolyTable(trace_polys)
-    ood_cur, ood_next = table.get_ood_frame(z, D)
-    q_cur, q_next = prover.composition_poly_ood_frame(comp_poly, z, D)
-    coin.reseed(hasher.hash_elements(np.concatenate([ood_cur.reshape(-1), ood_next.reshape(-1), q_cur.reshape(-1), q_next.reshape(-1)]), field=fld))
-    width = air.TRACE_WIDTH
-    cc_t, cc_c = np.stack([coin.draw(D) for _ in range(width)]), np.stack([coin.draw(D) for _ in range(ncols)])
-    deep = prover.DeepCompositionPoly(z, cc_t, cc_c, D)
-    deep.add_trace_polys(table, comp_poly, (ood_cur, ood_next), (q_cur, q_next))
-    assert deep.degree() == n - 2                                               # lib.rs:423
-    deep_ev = deep.evaluate(domain)
-    # ---- 5. FRI commit phase (lib.rs:433-440)
-    fopts = fri.FriOptions(blowup, folding, rem_deg, field=fld)
-    fchan = FriChannel(coin, D)
-    fprover = fri.FriProver(fopts, hasher, ext_degree=D)
-    fprover.build_layers(fchan, deep_ev)
-    # ---- 6. grinding + query positions (lib.rs:444-459)
-    nonce = crypto.grind_query_seed(hasher, coin.seed, grinding)
-    assert crypto.check_leading_zeros(hasher, coin.seed, nonce) >= grinding
-    positions = sorted(set(coin.draw_integers(num_queries, N, nonce)))
-    (t_rows, (t_leaves, t_proof)), = trace_lde.query(positions)
-    c_rows, (c_leaves, c_proof) = constraint_com.query(positions)
+    # ---- 2..6: the product's prove() (winterfell_amd/prover/prove.py), everything data-parallel on the device
+    options = prover.ProofOptions(num_queries, blowup, grinding, ext_degree=D, fri_folding_factor=folding, fri_remainder_max_degree=rem_deg)
+    proof = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, pub)
+    nt, ncols, width = air.num_transition_constraints(), air.num_constraint_composition_columns(), air.TRACE_WIDTH
+    cc, z, positions, nonce = proof.constraint_coefficients, proof.ood_point, proof.query_positions, proof.pow_nonce
+    (ood_cur, ood_next), (q_cur, q_next) = proof.ood_trace_frame, proof.ood_constraint_frame
+    cc_t, cc_c = proof.deep_coefficients
+    fopts = proof.fri_options
+    trace_root, constraint_root = proof.trace_commitment, proof.constraint_commitment
+    assert 0 < len(positions) <= num_queries and len(proof.commitments) == 2 + len(proof.fri_layers) + 1
+    (t_rows, (t_leaves, t_proof)), = proof.trace_queries
+    c_rows, (c_leaves, c_proof) = proof.constraint_queries
+
+    class _F:                                       # the names the checks below were written against
+        layers, remainder_poly = proof.fri_layers, proof.fri_remainder
+
+        @staticmethod
+        def num_layers():
+            return len(proof.fri_layers)
+
+    class _C:
+        commitments, alphas = proof.commitments[2:], proof.fri_alphas
+    fprover, fchan = _F, _C
 
     # ================= the checks a verifier would make =================
+    # (0) Fiat-Shamir replay: a fresh channel fed the proof's commitments and frames re-derives every challenge
+    #     (verifier/src/channel.rs + lib.rs:139-260), and the nonce satisfies the grinding condition
+    replay = prover.ProverChannel(air, options, hasher, pub)
+    replay.commit_trace(trace_root)
+    rcc = replay.get_constraint_composition_coeffs()
+    assert np.array_equal(rcc.transition, cc.transition) and np.array_equal(rcc.boundary, cc.boundary)
+    replay.commit_constraints(constraint_root)
+    assert np.array_equal(replay.get_ood_point(), z)
+    replay.send_ood_evaluations(proof.ood_trace_frame, proof.ood_constraint_frame)
+    rt, rc_ = replay.get_deep_composition_coeffs()
+    assert np.array_equal(rt, cc_t) and np.array_equal(rc_, cc_c)
+    for li in range(len(proof.fri_layers)):
+        replay.commit_fri_layer(proof.commitments[2 + li])
+        assert np.array_equal(replay.draw_fri_alpha(), proof.fri_alphas[li])
+    replay.commit_fri_layer(proof.commitments[-1])
+    assert np.array_equal(replay.public_coin.seed, proof.pow_seed)
+    assert crypto.check_leading_zeros(hasher, proof.pow_seed, nonce) >= grinding
+    assert nonce == 1 or all(crypto.check_leading_zeros(hasher, proof.pow_seed, v) < grinding for v in range(max(1, nonce - 8), nonce))
+    replay.pow_nonce = nonce
+    assert replay.get_query_positions() == positions
     # (a) Merkle openings of the queried rows against the two commitments
-    assert crypto.MerkleTree.verify_batch(hasher, trace_lde.get_main_trace_commitment(), positions, t_leaves, t_proof) is None
-    assert crypto.MerkleTree.verify_batch(hasher, constraint_com.commitment(), positions, c_leaves, c_proof) is None
+    assert crypto.MerkleTree.verify_batch(hasher, trace_root, positions, t_leaves, t_proof) is None
+    assert crypto.MerkleTree.verify_batch(hasher, constraint_root, positions, c_leaves, c_proof) is None
     lv = hasher.hash_elements(np.ascontiguousarray(t_rows), field=fld)
     assert all(np.array_equal(lv[k], t_leaves[k]) for k in range(len(positions)))
     # (b) the OOD constraint equation (verifier/src/evaluator.rs:16-89 vs sum_i z^(i n) H_i(z))
@@ -145,7 +106,7 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
     tev = fld.unpack(ofld.air_evaluate_transition(air_id, D, ood_cur.reshape(-1), ood_next.reshape(-1), per))
     assert ood_constraint_equation_holds(E, one, g, n, zi, H, [tev[k * D:(k + 1) * D] for k in range(nt)],
                                          [fld.unpack(c) for c in cc.transition], [fld.unpack(r) for r in ood_cur],
-                                         [(a.column, a.first_step, a.value) for a in evaluator.assertions],
+                                         [(a.column, a.first_step, a.value) for a in proof.assertions],
                                          [fld.unpack(c) for c in cc.boundary])
     # (c) DEEP composition at every query position from the opened rows (verifier/src/composer.rs)
     g_lde = fld.new(fld.get_root_of_unity(N.bit_length() - 1))
@@ -174,8 +135,8 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
     for li, layer in enumerate(fprover.layers):
         rc = length // folding
         rows_idx = sorted(set(p % rc for p in pos))
-        leaves, proof = layer.commitment.prove_batch(rows_idx)
-        assert crypto.MerkleTree.verify_batch(hasher, fchan.commitments[li], rows_idx, leaves, proof) is None
+        leaves, mproof = layer.commitment.prove_batch(rows_idx)
+        assert crypto.MerkleTree.verify_batch(hasher, fchan.commitments[li], rows_idx, leaves, mproof) is None
         rows = ctx.to_host(layer.evaluations)
         nxt_rows = ctx.to_host(fprover.layers[li + 1].evaluations) if li + 1 < len(fprover.layers) else None
         for r in rows_idx:

@@ -38,3 +38,49 @@ def grind_query_seed(hasher, seed, grinding_factor, first_nonce=1, max_nonce=(1 
             raise RuntimeError("nonce not found") from e
         raise
     return int(nonce.value)
+
+
+class DefaultRandomCoin:
+    """crypto::DefaultRandomCoin (crypto/src/random/default.rs): seed / reseed / draw over one of the library's hashers.
+    Sequential host logic (one small hash per call), kept here so the Python mirror can drive a whole proof; in a real
+    integration this is the reference's own Rust coin.  `field` is the base field (a fields.Field)."""
+
+    def __init__(self, hasher, field, seed_elements, ctx=None):
+        self.hasher, self.field, self.ctx = hasher, field, ctx
+        self.seed = hasher.hash_elements(np.ascontiguousarray(seed_elements, dtype=np.uint64), ctx, field=field)   # :114-117
+        self.counter = 0
+
+    def reseed(self, data):
+        """seed = merge(seed, data); counter = 0 (:150-153)"""
+        self.seed = self.hasher.merge(np.stack([self.seed, np.asarray(data, dtype=np.uint8).reshape(32)]), self.ctx)
+        self.counter = 0
+
+    def _next(self):
+        """merge_with_int(seed, ++counter) as Digest::as_bytes (:92-98)"""
+        self.counter += 1
+        return self.hasher.digest_as_bytes(self.hasher.merge_with_int(self.seed, self.counter, ctx=self.ctx))
+
+    def draw(self, ext_degree=1):
+        """draw::<E> (:185-199): the first ELEMENT_BYTES of next() must decode to canonical base elements; up to 1000 tries.
+        Returns ext_degree * W words (internal form)."""
+        f = self.field
+        nb = 8 * f.W
+        for _ in range(1000):
+            b = self._next()
+            if len(b) < ext_degree * nb:
+                raise RuntimeError("digest too short for the requested element")
+            vals = [int.from_bytes(b[k * nb:(k + 1) * nb], "little") for k in range(ext_degree)]
+            if all(v < f.M for v in vals):
+                return f.pack([f.new(v) for v in vals])
+        raise RuntimeError("FailedToDrawFieldElement(1000)")
+
+    def check_leading_zeros(self, value):
+        return check_leading_zeros(self.hasher, self.seed, value, ctx=self.ctx)
+
+    def draw_integers(self, num_values, domain_size, nonce):
+        """:209-248: reseed with the nonce, then masked 8-byte heads (duplicates are removed by the caller)."""
+        assert domain_size & (domain_size - 1) == 0, "domain size must be a power of two"
+        assert num_values < domain_size, "number of values must be smaller than domain size"
+        self.seed = self.hasher.merge_with_int(self.seed, nonce, ctx=self.ctx)
+        self.counter = 0
+        return [int.from_bytes(self._next()[:8], "little") & (domain_size - 1) for _ in range(num_values)]

@@ -1,0 +1,84 @@
+"""ProverChannel (prover/src/channel.rs:17-215): the prover's side of the Fiat-Shamir transcript.
+
+Host logic around a DefaultRandomCoin; the one data-parallel step, grind_query_seed, runs on the GPU.  The coin is seeded
+with the public inputs and the proof parameters; the byte-level serialisation of the reference's `Context` is not
+reproduced (proof objects are out of scope), so transcripts produced here are self-consistent but not
+byte-compatible with the Rust prover's."""
+import numpy as np
+
+from ..crypto.random import DefaultRandomCoin, grind_query_seed
+from .constraints import ConstraintCompositionCoefficients
+
+
+class ProofOptions:
+    """air::ProofOptions (air/src/options.rs:88-118), the fields the prover pipeline needs."""
+
+    def __init__(self, num_queries, blowup_factor, grinding_factor, ext_degree=1, fri_folding_factor=4, fri_remainder_max_degree=31):
+        assert 0 < num_queries <= 255 and blowup_factor >= 2 and blowup_factor & (blowup_factor - 1) == 0 and grinding_factor <= 32
+        self.num_queries, self.blowup_factor, self.grinding_factor = num_queries, blowup_factor, grinding_factor
+        self.ext_degree, self.fri_folding_factor, self.fri_remainder_max_degree = ext_degree, fri_folding_factor, fri_remainder_max_degree
+
+
+class ProverChannel:
+    def __init__(self, air, options: ProofOptions, hasher, pub_inputs_elements, ctx=None):
+        f = air.FIELD
+        self.air, self.options, self.hasher, self.ctx = air, options, hasher, ctx
+        context = [air.TRACE_WIDTH, air.trace_length(), options.blowup_factor, options.num_queries, options.grinding_factor,
+                   options.ext_degree, options.fri_folding_factor, options.fri_remainder_max_degree,
+                   air.num_assertions() + air.num_transition_constraints()]
+        seed = f.pack([f.new(v) for v in context] + list(pub_inputs_elements))
+        self.public_coin = DefaultRandomCoin(hasher, f, seed, ctx)
+        self.commitments, self.fri_alphas = [], []
+        self.ood_frame = None
+        self.pow_nonce, self.pow_seed = 0, None
+
+    # ---- commitments (channel.rs:87-110)
+    def commit_trace(self, trace_root):
+        self.commitments.append(np.array(trace_root, copy=True))
+        self.public_coin.reseed(trace_root)
+
+    def commit_constraints(self, constraint_root):
+        self.commitments.append(np.array(constraint_root, copy=True))
+        self.public_coin.reseed(constraint_root)
+
+    def send_ood_evaluations(self, trace_ood_frame, constraints_ood_frame):
+        """merge_ood_evaluations (air/src/proof/ood_frame.rs:335-351): current rows (trace, quotient), then next rows."""
+        (tc, tn), (qc, qn) = trace_ood_frame, constraints_ood_frame
+        self.ood_frame = (trace_ood_frame, constraints_ood_frame)
+        evals = np.concatenate([np.asarray(tc).reshape(-1), np.asarray(qc).reshape(-1), np.asarray(tn).reshape(-1), np.asarray(qn).reshape(-1)])
+        self.public_coin.reseed(self.hasher.hash_elements(evals, self.ctx, field=self.air.FIELD))
+
+    # ---- public coin (channel.rs:112-165); linear batching: one draw per coefficient (air/src/air/coefficients.rs:201-206)
+    def get_constraint_composition_coeffs(self):
+        D = self.options.ext_degree
+        t = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_transition_constraints())])
+        b = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_assertions())])
+        return ConstraintCompositionCoefficients(t, b)
+
+    def get_ood_point(self):
+        return self.public_coin.draw(self.options.ext_degree)
+
+    def get_deep_composition_coeffs(self):
+        D = self.options.ext_degree
+        trace = np.stack([self.public_coin.draw(D) for _ in range(self.air.TRACE_WIDTH)])
+        constraints = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_constraint_composition_columns())])
+        return trace, constraints
+
+    # ---- fri::ProverChannel (fri/src/prover/channel.rs:24-50)
+    def commit_fri_layer(self, layer_root):
+        self.commitments.append(np.array(layer_root, copy=True))
+        self.public_coin.reseed(layer_root)
+
+    def draw_fri_alpha(self):
+        a = self.public_coin.draw(self.options.ext_degree)
+        self.fri_alphas.append(a)
+        return a
+
+    # ---- query phase (channel.rs:146-185)
+    def grind_query_seed(self):
+        self.pow_seed = np.array(self.public_coin.seed, copy=True)
+        self.pow_nonce = grind_query_seed(self.hasher, self.public_coin.seed, self.options.grinding_factor, ctx=self.ctx)
+
+    def get_query_positions(self):
+        positions = self.public_coin.draw_integers(self.options.num_queries, self.air.lde_domain_size(), self.pow_nonce)
+        return sorted(set(positions))
