@@ -198,13 +198,25 @@ class MerkleTree {
         if (h_leaves_.empty()) h_leaves_ = leaves_.to_host<uint8_t>();
         return h_leaves_;
     }
-    std::vector<uint8_t> root() const { return std::vector<uint8_t>(nodes().begin() + 32, nodes().begin() + 64); }
+    // digests at `positions` of the leaf / node array: one device gather (wf_rows_fetch, 32-byte rows) — an opening touches
+    // depth + 1 of the 2n digests, so the tree stays in HBM unless nodes() / leaves() were asked for explicitly
+    std::vector<uint8_t> fetch(const DeviceBuffer &from, const std::vector<uint64_t> &positions) const {
+        std::vector<uint8_t> out(positions.size() * 32);
+        if (!positions.empty())
+            check(wf_rows_fetch(from.ctx().handle(), from.data(), 4, 4, 8, positions.data(), (uint32_t)positions.size(), out.data()), "wf_rows_fetch");
+        return out;
+    }
+    std::vector<uint8_t> root() const { return fetch(nodes_, {1}); }
     // MerkleTree::prove (mod.rs:193-215): [leaf, sibling leaf, then the sibling node of every level up to the root]
     std::vector<std::vector<uint8_t>> prove(uint64_t index) const {
         if (index >= n_) throw std::out_of_range("LeafIndexOutOfBounds");
         auto digest = [](const std::vector<uint8_t> &v, uint64_t i) { return std::vector<uint8_t>(v.begin() + 32 * i, v.begin() + 32 * (i + 1)); };
-        std::vector<std::vector<uint8_t>> out{digest(leaves(), index), digest(leaves(), index ^ 1)};
-        for (uint64_t i = (index + n_) >> 1; i > 1; i >>= 1) out.push_back(digest(nodes(), i ^ 1));
+        const std::vector<uint8_t> lv = fetch(leaves_, {index, index ^ 1});
+        std::vector<uint64_t> path;
+        for (uint64_t i = (index + n_) >> 1; i > 1; i >>= 1) path.push_back(i ^ 1);
+        const std::vector<uint8_t> nd = fetch(nodes_, path);
+        std::vector<std::vector<uint8_t>> out{digest(lv, 0), digest(lv, 1)};
+        for (uint64_t k = 0; k < path.size(); k++) out.push_back(digest(nd, k));
         return out;
     }
 

@@ -5,6 +5,8 @@ nodes[n/2..n) = parents of leaf pairs; mod.rs:344-368) so openings read it exact
 Openings (prove / prove_batch) are index walks over that array and stay on the host, as in the reference;
 verification recomputes merges with the GPU hasher.
 """
+import ctypes
+
 import numpy as np
 
 from .._lib import WfError, default_context, ptr
@@ -108,6 +110,7 @@ class MerkleTree:
     # ---- accessors ----------------------------------------------------------------------------------------
     @property
     def nodes(self):
+        """the whole node array on the host (copied once, on first use; openings below do not need it)"""
         if self._nodes is None:
             self._nodes = self.ctx.to_host(self._nodes_dev).reshape(-1, 32)
         return self._nodes
@@ -122,28 +125,47 @@ class MerkleTree:
     def nodes_device(self):
         return self._nodes_dev
 
+    def num_leaves(self):
+        return self._leaves_dev.numel() // 32
+
+    def _fetch(self, which, idxs):
+        """digests at the given positions of the leaf ('L') or node ('N') array: from the host copy when one exists,
+        otherwise one gather on the device (wf_rows_fetch, 32-byte rows) — a query touches ~depth * num_queries of the
+        2n digests, so the tree itself stays in HBM."""
+        host = self._leaves if which == "L" else self._nodes
+        if host is not None:
+            return host[np.asarray(idxs, dtype=np.int64)]
+        dev = self._leaves_dev if which == "L" else self._nodes_dev
+        pos = np.ascontiguousarray(idxs, dtype=np.uint64)
+        out = np.empty((len(pos), 32), dtype=np.uint8)
+        if len(pos):
+            self.ctx.call("wf_rows_fetch", ptr(dev), 4, 4, 8, pos.ctypes.data_as(ctypes.c_void_p), len(pos),
+                          out.ctypes.data_as(ctypes.c_void_p))
+        return out
+
     def root(self):
-        return self.nodes[1]
+        return self._fetch("N", [1])[0]
 
     def depth(self):
-        return len(self.leaves).bit_length() - 1
+        return self.num_leaves().bit_length() - 1
 
     # ---- openings (mod.rs:193-272) ------------------------------------------------------------------------
     def prove(self, index):
-        n = len(self.leaves)
+        n = self.num_leaves()
         if index >= n:
             raise MerkleTreeError("LeafIndexOutOfBounds(%d, %d)" % (n, index))
-        proof = [self.leaves[index ^ 1]]
+        lv = self._fetch("L", [index, index ^ 1])
+        path = []
         i = (index + n) >> 1
         while i > 1:
-            proof.append(self.nodes[i ^ 1])
+            path.append(i ^ 1)
             i >>= 1
-        return self.leaves[index], proof
+        return lv[0], [lv[1]] + list(self._fetch("N", path))
 
     def prove_batch(self, indexes):
         if len(indexes) == 0:
             raise MerkleTreeError("TooFewLeafIndexes")
-        n = len(self.leaves)
+        n = self.num_leaves()
         index_map = {}
         for pos, idx in enumerate(indexes):
             if idx >= n:
@@ -151,17 +173,20 @@ class MerkleTree:
             index_map[idx] = pos
         if len(index_map) != len(indexes):
             raise MerkleTreeError("DuplicateLeafIndex")
+        # pass 1: the index walk of mod.rs:217-272, recording WHICH digests go where; pass 2 fetches them in two gathers
         pairs = sorted({i - (i & 1) for i in indexes})
-        leaves = [None] * len(index_map)
-        nodes = []
+        want_l, want_n = [], []                      # positions in the leaf / node arrays
+        leaf_slots = [None] * len(index_map)         # -> index into want_l
+        nodes = []                                   # per pair: list of ('L' | 'N', index into want_*)
         nxt = []
         for p in pairs:
             missing = []
             for i in (p, p + 1):
+                want_l.append(i)
                 if i in index_map:
-                    leaves[index_map[i]] = self.leaves[i]
+                    leaf_slots[index_map[i]] = len(want_l) - 1
                 else:
-                    missing.append(self.leaves[i])
+                    missing.append(("L", len(want_l) - 1))
             nodes.append(missing)
             nxt.append((p + n) >> 1)
         for _ in range(1, self.depth()):
@@ -172,10 +197,13 @@ class MerkleTree:
                 if i + 1 < len(cur) and cur[i + 1] == sib:
                     i += 1
                 else:
-                    nodes[i].append(self.nodes[sib])
+                    want_n.append(sib)
+                    nodes[i].append(("N", len(want_n) - 1))
                 nxt.append(sib >> 1)
                 i += 1
-        return leaves, BatchMerkleProof(nodes, self.depth())
+        got = {"L": self._fetch("L", want_l), "N": self._fetch("N", want_n)}
+        leaves = [got["L"][k] for k in leaf_slots]
+        return leaves, BatchMerkleProof([[got[w][k] for w, k in lst] for lst in nodes], self.depth())
 
     # ---- verification (mod.rs:283-307) ----------------------------------------------------------------------
     @staticmethod

@@ -87,7 +87,20 @@ GL_HD uint64_t mul(uint64_t a, uint64_t b) {
     return mont_red((uint64_t)x, (uint64_t)(x >> 64));
 }
 
-GL_HD uint64_t sqr(uint64_t a) { return mul(a, a); }
+// Montgomery square with three multiplies and no carry chain in the product:  a^2 = a0^2 + 2^33 a0 a1 + 2^64 a1^2;
+// with a0^2 = l + 2^33 h (l < 2^33, h < 2^31) and u = a0 a1 + h (< 2^64):  a^2 = l + 2^33 u + 2^64 a1^2, so the low word is
+// l | (u << 33) and the high word a1^2 + (u >> 31) (< 2^64), both mad addends.  (The compiler's 64x64 product keeps
+// a0*a1 and a1*a0 as two multiplies.)  Rescue's x^(1/7) is 66 of these per state word.
+GL_HD uint64_t sqr(uint64_t a) {
+    const u32 a0 = (u32)a, a1 = (u32)(a >> 32);
+    const uint64_t p00 = (uint64_t)a0 * a0;
+    const u32 p00h = (u32)(p00 >> 32);
+    const uint64_t u = (uint64_t)a0 * a1 + (p00h >> 1);
+    const u32 ul = (u32)u, uh = (u32)(u >> 32);
+    const u32 x1 = (ul << 1) | (p00h & 1u);
+    const uint64_t hi = (uint64_t)a1 * a1 + join(funnel(uh, ul, 31), uh >> 31);
+    return mont_red(join((u32)p00, x1), hi);
+}
 
 // canonical integer of an internal value (mont_to_int, f64/mod.rs:731-737)
 GL_HD uint64_t to_int(uint64_t a) { return mont_red(a, 0); }
