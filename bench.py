@@ -186,6 +186,20 @@ def main():
             tt = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             sharded["sharded_fri_build_layers_ms_2^24_quad_fold4_blake3"] = float(tt.item())
+            # the same commit phase in the verifier's partitioned layout (FriProof.num_partitions = N):
+            # rank k folds the positions = k (mod N); only the 32-byte sub-roots cross xGMI
+            prun = lambda: parallel.partitioned_fri_build_layers(fbackend, fopts, _Chan(), piece, 2)
+            prun()
+            ts = []
+            for _ in range(3):
+                barrier()
+                t1 = time.perf_counter()
+                prun()
+                barrier()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            tt = torch.tensor([float(np.median(ts))], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            sharded["partitioned_fri_build_layers_ms_2^24_quad_fold4_blake3"] = float(tt.item())
             del piece
         except Exception as e:
             sharded["sharded_fri_error"] = repr(e)[:200]

@@ -169,3 +169,46 @@ def test_sharded_fri_emulation_equals_single_device(wf, oracle, world, hname, D,
         assert np.array_equal(full, ref.layers[k].commitment.nodes)
     for k, (trows, tnodes) in enumerate(results[0]["tail"]):
         assert np.array_equal(tnodes, ref.layers[nsh + k].commitment.nodes)
+
+
+@pytest.mark.parametrize("world,hname,D,log_len,N", [(2, "Blake3_256", 2, 14, 4), (8, "Blake3_256", 1, 15, 2), (4, "Rp64_256", 3, 12, 8),
+                                                      (8, "Blake3_256", 2, 16, 16), (1, "Blake3_256", 2, 12, 4)])
+def test_partitioned_fri_emulation_equals_verifier_layout(wf, oracle, world, hname, D, log_len, N):
+    """SURVEY 8e layout (ii): P logical ranks on one device, rank k folding the positions = k (mod P) with the plain local
+    kernels (wf_fri_layer_commit / wf_fri_apply_drp_rows over the coset offset * g^k), no evaluation exchange.  Checked against
+    the single-process restatement whose leaves are placed by the reference verifier's map_positions_to_indexes
+    (fri/src/utils.rs:9-33); with P = 1 that is the ordinary prover."""
+    ctx, crypto, fri, fields = wf
+    from fri_partition_util import fold_positions, oracle_partitioned_fri
+    from winterfell_amd import parallel
+    hasher = getattr(crypto, hname)
+    hid = 0 if hname == "Blake3_256" else 1
+    blowup = 8
+    ev_h = _lde_of_random_poly(oracle, log_len, blowup, D, 11 * world + N)
+    opts = fri.FriOptions(blowup, N, 7)
+    ochan = oracle.ProverChannel(hid, D)
+    want_layers, want_rem = oracle_partitioned_fri(oracle, hid, D, opts, ochan, ev_h.copy(), world)
+    results, chans = parallel.emulated_partitioned_fri(lambda: parallel.HipFriBackend(hasher, fields.f64, D, ctx), opts,
+                                                       lambda: oracle.ProverChannel(hid, D), ctx.to_device(ev_h), D, world)
+    assert len(want_layers) >= 2
+    positions, length = [3, 1 << (log_len - 1), (1 << log_len) - 1, 12345 % (1 << log_len)], 1 << log_len
+    for r in range(world):
+        assert len(results[r]["layers"]) == len(want_layers)
+        assert all(np.array_equal(a, b) for a, b in zip(chans[r].commitments, ochan.commitments))
+        assert np.array_equal(results[r]["remainder"], want_rem)
+    for k, (rows, leaves, nodes) in enumerate(want_layers):
+        rc = rows.shape[0]
+        for r in range(world):
+            lay = results[r]["layers"][k]
+            assert np.array_equal(ctx.to_host(lay["rows"]), rows[r::world])
+            assert np.array_equal(ctx.to_host(lay["leaves"]), leaves[r * (rc // world):(r + 1) * (rc // world)])
+        if world > 1:
+            full = parallel.assemble_nodes(world, rc, [ctx.to_host(results[r]["layers"][k]["nodes"]) for r in range(world)],
+                                           ctx.to_host(results[0]["layers"][k]["top"]))
+            assert np.array_equal(full, nodes)
+        else:
+            assert np.array_equal(ctx.to_host(results[0]["layers"][k]["nodes"])[1:], nodes[1:])
+        positions = fold_positions(positions, length, N)
+        for p, i in zip(positions, parallel.map_positions_to_indexes(positions, length, N, world)):
+            assert np.array_equal(leaves[i], oracle.hash_elements(hid, rows[p]))
+        length = rc

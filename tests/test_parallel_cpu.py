@@ -301,3 +301,84 @@ def test_strided_commit_equals_default_single_process(oracle, tmp_path, world, h
         assert np.array_equal(got[r]["lde"], lde[r::world])                       # rank r holds rows r, r + G, r + 2G, ...
     full = parallel.assemble_nodes(world, N, [g["nodes"] for g in got], got[0]["top"])
     assert np.array_equal(full, nodes)
+
+
+# ---- FRI commit phase in the verifier's partitioned layout (SURVEY 8e layout (ii)) --------------------------------------
+def test_map_positions_to_indexes_is_the_verifiers_mapping():
+    """fri/src/utils.rs:9-33: P = 1 is the identity; otherwise partition p % P, local index p // P, partition size
+    (source / N) / P — a bijection of the folded domain that puts every partition's positions in one contiguous block."""
+    from winterfell_amd.parallel import map_positions_to_indexes
+    assert map_positions_to_indexes([5, 1, 7], 64, 4, 1) == [5, 1, 7]
+    assert map_positions_to_indexes([0, 1, 2, 3, 9], 64, 4, 4) == [0, 4, 8, 12, 6]
+    for src, N, P in [(64, 4, 4), (256, 2, 8), (1 << 12, 16, 2)]:
+        rc = src // N
+        idx = map_positions_to_indexes(list(range(rc)), src, N, P)
+        assert sorted(idx) == list(range(rc))
+        for k in range(P):
+            assert [idx[k + P * q] for q in range(rc // P)] == list(range(k * (rc // P), (k + 1) * (rc // P)))
+
+
+def _pfri_worker(rank, world, port, hasher_id, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from winterfell_amd import parallel
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    D, N, opts, ev = _fri_case(world)
+    piece = torch.from_numpy(ev.reshape(-1, world, D)[:, rank, :].copy().reshape(-1))      # e[rank + world * m]
+    chan = oracle.ProverChannel(hasher_id, D)
+    res = parallel.partitioned_fri_build_layers(_OracleFriBackend(hasher_id, D), opts, chan, piece, D)
+    np.savez(os.path.join(out_dir, "pfri%d.npz" % rank), nlayers=len(res["layers"]), remainder=res["remainder"],
+             commitments=np.stack(chan.commitments),
+             **{"rows%d" % k: l["rows"].numpy() for k, l in enumerate(res["layers"])},
+             **{"leaves%d" % k: l["leaves"].numpy() for k, l in enumerate(res["layers"])},
+             **{"nodes%d" % k: l["nodes"].numpy() for k, l in enumerate(res["layers"])},
+             **{"top%d" % k: l["top"].numpy() for k, l in enumerate(res["layers"])})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,hasher_id", [(2, 0), (4, 1), (8, 0)])
+def test_partitioned_fri_equals_verifier_layout(oracle, tmp_path, world, hasher_id):
+    """Rank k folds the positions = k (mod P) with no evaluation exchange; the layer trees must be the single-process
+    trees built over leaves placed by the verifier's map_positions_to_indexes, the transcript and the remainder the ones
+    of that single-process run, and every queried row must sit where the verifier will look for it."""
+    import torch.multiprocessing as mp
+    from fri_partition_util import fold_positions, oracle_partitioned_fri
+    from winterfell_amd import parallel
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_pfri_worker, args=(world, port, hasher_id, str(tmp_path)), nprocs=world, join=True)
+    D, N, opts, ev = _fri_case(world)
+    ochan = oracle.ProverChannel(hasher_id, D)
+    want_layers, want_rem = oracle_partitioned_fri(oracle, hasher_id, D, opts, ochan, ev.copy(), world)
+    got = [np.load(os.path.join(str(tmp_path), "pfri%d.npz" % r)) for r in range(world)]
+    assert int(got[0]["nlayers"]) == len(want_layers) == 3
+    positions, length = [5, 77, 1234, 4095, 2048, 77 + 1024], ev.size // D
+    for r in range(world):
+        assert np.array_equal(got[r]["commitments"], np.stack(ochan.commitments))
+        assert np.array_equal(got[r]["remainder"], want_rem)
+    for k, (rows, leaves, nodes) in enumerate(want_layers):
+        rc = rows.shape[0]
+        for r in range(world):
+            assert np.array_equal(got[r]["rows%d" % k], rows[r::world])                       # global row r + P*q at local q
+            assert np.array_equal(got[r]["leaves%d" % k], leaves[r * (rc // world):(r + 1) * (rc // world)])
+        full = parallel.assemble_nodes(world, rc, [g["nodes%d" % k] for g in got], got[0]["top%d" % k])
+        assert np.array_equal(full, nodes)
+        # the verifier's look-up: folded position p -> leaf map(p), which must be the hash of transposed row p
+        positions = fold_positions(positions, length, N)
+        for p, i in zip(positions, parallel.map_positions_to_indexes(positions, length, N, world)):
+            assert np.array_equal(leaves[i], oracle.hash_elements(hasher_id, rows[p]))
+            assert np.array_equal(got[p % world]["leaves%d" % k][p // world], leaves[i])
+        length = rc
+
+
+def test_partitioned_fri_rejects_too_many_partitions():
+    from winterfell_amd import parallel
+    from winterfell_amd.fri import FriOptions
+    with pytest.raises(ValueError):
+        parallel._partitioned_layer_plan(FriOptions(8, 4, 7), 1 << 8, 128)      # 2^8 -> rows 64: not a multiple of 128

@@ -29,4 +29,18 @@ for name in names:
         m.commit_to_rows(h)
     agg = ctx.prof_collect()
     ctx.prof_enable(False)
-    print(name, "rows 2^%d x %d:" % (log_rows, cols), "  ".join("%s %.3f ms" % (k.split("<")[0], v[1] / v[0]) for k, v in sorted(agg.items())))
+    print(name, "rows 2^%d x %d:" % (log_rows, cols), "  ".join("%s %d launches, %.3f ms per commit" % (k.split("<")[0], v[0] // 3, v[1] / 3) for k, v in sorted(agg.items())))
+    # small trees: latency of the upper levels (what FRI layers and partition sub-trees look like)
+    import time
+    for lg in (8, 12, 15, 18):
+        if lg >= log_rows:
+            continue
+        lv = ctx.empty_u8(1 << lg, 32)
+        lv.copy_(m.hash_rows(h)[: 1 << lg])
+        crypto.MerkleTree.new(h, lv, ctx)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(5):
+            crypto.MerkleTree.new(h, lv, ctx)
+        torch.cuda.synchronize()
+        print("   merkle 2^%d leaves: %.3f ms" % (lg, (time.perf_counter() - t) / 5 * 1e3))

@@ -49,16 +49,27 @@ class DefaultRandomCoin:
         self.hasher, self.field, self.ctx = hasher, field, ctx
         self.seed = hasher.hash_elements(np.ascontiguousarray(seed_elements, dtype=np.uint64), ctx, field=field)   # :114-117
         self.counter = 0
+        self._ahead = []            # as_bytes of merge_with_int(seed, counter + 1 + k): a run of counters is ONE device batch
 
     def reseed(self, data):
         """seed = merge(seed, data); counter = 0 (:150-153)"""
         self.seed = self.hasher.merge(np.stack([self.seed, np.asarray(data, dtype=np.uint8).reshape(32)]), self.ctx)
-        self.counter = 0
+        self.counter, self._ahead = 0, []
+
+    def prefetch(self, count):
+        """evaluate the next `count` values of next() in one batch (wf_hash_merge_with_int_batch); pure look-ahead — the
+        values are exactly those the sequential calls would produce, so the transcript does not change"""
+        if count > len(self._ahead):
+            first = self.counter + 1 + len(self._ahead)
+            rows = self.hasher.merge_with_int(self.seed, first, count - len(self._ahead), ctx=self.ctx)
+            self._ahead.extend(self.hasher.digest_as_bytes(r) for r in rows)
 
     def _next(self):
         """merge_with_int(seed, ++counter) as Digest::as_bytes (:92-98)"""
+        if not self._ahead:
+            self.prefetch(1)
         self.counter += 1
-        return self.hasher.digest_as_bytes(self.hasher.merge_with_int(self.seed, self.counter, ctx=self.ctx))
+        return self._ahead.pop(0)
 
     def draw(self, ext_degree=1):
         """draw::<E> (:185-199): the first ELEMENT_BYTES of next() must decode to canonical base elements; up to 1000 tries.
@@ -74,6 +85,11 @@ class DefaultRandomCoin:
                 return f.pack([f.new(v) for v in vals])
         raise RuntimeError("FailedToDrawFieldElement(1000)")
 
+    def draw_many(self, count, ext_degree=1):
+        """`count` consecutive draws (what the channel's get_*_coeffs loops do), the hashes batched"""
+        self.prefetch(count)
+        return np.stack([self.draw(ext_degree) for _ in range(count)])
+
     def check_leading_zeros(self, value):
         return check_leading_zeros(self.hasher, self.seed, value, ctx=self.ctx)
 
@@ -82,5 +98,6 @@ class DefaultRandomCoin:
         assert domain_size & (domain_size - 1) == 0, "domain size must be a power of two"
         assert num_values < domain_size, "number of values must be smaller than domain size"
         self.seed = self.hasher.merge_with_int(self.seed, nonce, ctx=self.ctx)
-        self.counter = 0
+        self.counter, self._ahead = 0, []
+        self.prefetch(num_values)
         return [int.from_bytes(self._next()[:8], "little") & (domain_size - 1) for _ in range(num_values)]

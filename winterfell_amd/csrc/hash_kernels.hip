@@ -16,6 +16,7 @@
 #include "rp62.cuh"
 #include "rp64.cuh"
 #include "rpjive64.cuh"
+#include "rescue_coop.cuh"
 #include "wf_internal.h"
 
 namespace {
@@ -29,6 +30,7 @@ struct Digest {
 
 // ---- per-hasher primitives on 32-byte digests ----------------------------------------------------------------
 struct HBlake3 {
+    static constexpr bool COOP = false;
     // levels reduced per Merkle launch: BLAKE3 merges are cheap, so a workgroup walks 10 levels through LDS
     static constexpr uint32_t STAGE_LEVELS = 10;
     static const char *row_name() { return "hash_rows_blake3"; }
@@ -68,6 +70,7 @@ struct HBlake3 {
 // 32-byte slots with bytes 24..31 zero; what is hashed is the reference's byte string (48 bytes for a merge, 24 k bytes
 // for merge_many, seed[..24] || value for merge_with_int).
 struct HBlake3_192 {
+    static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 10;
     static const char *row_name() { return "hash_rows_blake3_192"; }
     static const char *merkle_name() { return "merkle_stage_blake3_192"; }
@@ -114,6 +117,8 @@ struct HBlake3_192 {
 
 // RpJive64_256 (crypto/src/hash/rescue/rp64_256_jive/mod.rs): ElementDigest like Rp64_256, width-8 permutation
 struct HRpJive {
+    static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
+    typedef rcoop::CoopRpJive Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;      // as for Rp64_256: one full-width level per launch
     static const char *row_name() { return "hash_rows_rpjive"; }
     static const char *merkle_name() { return "merkle_stage_rpjive"; }
@@ -167,6 +172,7 @@ struct HRpJive {
 
 // Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs): four f62 words per digest, defined over f62 only
 struct HRp62 {
+    static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 1;
     static const char *row_name() { return "hash_rows_rp62"; }
     static const char *merkle_name() { return "merkle_stage_rp62"; }
@@ -220,6 +226,7 @@ struct HRp62 {
 
 // Sha3_256<B> (crypto/src/hash/sha/mod.rs:21-66): same byte-level structure as Blake3_256 with SHA3-256 as the byte hash
 struct HSha3 {
+    static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 8;
     static const char *row_name() { return "hash_rows_sha3"; }
     static const char *merkle_name() { return "merkle_stage_sha3"; }
@@ -259,6 +266,8 @@ struct HSha3 {
 };
 
 struct HRp64 {
+    static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
+    typedef rcoop::CoopRp64 Coop;
     // a Rescue merge is ~6400 modmuls (0.2 ms of one wave): the nearly empty upper levels of a multi-level workgroup
     // would serialise ten such latencies per workgroup, so the tree is built one full-width level per launch
     static constexpr uint32_t STAGE_LEVELS = 1;
@@ -448,6 +457,16 @@ int launch_hash_rows_t(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uin
                        uint32_t part_elems, uint32_t parts, void *out) {
     const uint64_t blocks = (num_rows + 255) / 256;
     if (blocks > 0x7fffffffull || parts > 65535) return WF_ERR_DOMAIN_TOO_LARGE;
+    if constexpr (H::COOP) {
+        if (num_rows * parts <= rcoop::COOP_MAX) {      // few rows: latency-bound, spread each state over 16 lanes
+            wf_prof_begin(ctx, H::row_name());
+            hipLaunchKernelGGL((rcoop::hash_rows_kernel<typename H::Coop>), dim3((uint32_t)((num_rows + 15) / 16), parts), dim3(256), 0,
+                               ctx->stream, rows, num_rows, row_width, elems_per_row, part_elems, parts, (uint64_t *)out);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            return WF_OK;
+        }
+    }
     wf_prof_begin(ctx, H::row_name());
     hipLaunchKernelGGL((hash_rows_kernel<H, MODE, MULTI>), dim3((uint32_t)blocks, parts), dim3(256), 0, ctx->stream, rows,
                        num_rows, row_width, elems_per_row, part_elems, parts, out);
@@ -485,8 +504,17 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
             const uint64_t blocks = (half + 255) / 256;
             if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
             wf_prof_begin(ctx, H::merkle_name());
-            hipLaunchKernelGGL(merge_batch_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, (const void *)in, half,
-                               (void *)((uint8_t *)nodes + half * 32));
+            bool coop = false;
+            if constexpr (H::COOP) {
+                if (half <= rcoop::COOP_MAX) {           // the upper levels: one 0.2 ms wave per 64 merges otherwise
+                    coop = true;
+                    hipLaunchKernelGGL((rcoop::merge_kernel<typename H::Coop>), dim3((uint32_t)((half + 15) / 16)), dim3(256), 0, ctx->stream,
+                                       (const uint64_t *)in, half, (uint64_t *)((uint8_t *)nodes + half * 32));
+                }
+            }
+            if (!coop)
+                hipLaunchKernelGGL(merge_batch_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, (const void *)in, half,
+                                   (void *)((uint8_t *)nodes + half * 32));
             wf_prof_end(ctx);
             WF_HIP(hipGetLastError());
             count = half;
@@ -543,7 +571,15 @@ extern "C" int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, u
     const uint64_t blocks = (count + 255) / 256;
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
     WF_TRY(with_hasher(hash, [&](auto h) {
-        hipLaunchKernelGGL(merge_batch_kernel<decltype(h)>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
+        typedef decltype(h) H;
+        if constexpr (H::COOP) {
+            if (count <= rcoop::COOP_MAX) {
+                hipLaunchKernelGGL((rcoop::merge_kernel<typename H::Coop>), dim3((uint32_t)((count + 15) / 16)), dim3(256), 0, ctx->stream,
+                                   (const uint64_t *)d_pairs, count, (uint64_t *)d_out);
+                return (int)WF_OK;
+            }
+        }
+        hipLaunchKernelGGL(merge_batch_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, d_pairs, count, d_out);
         return (int)WF_OK;
     }));
     WF_HIP(hipGetLastError());
@@ -628,7 +664,17 @@ extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h
     Seed seed;
     memcpy(seed.w, h_seed, 32);
     WF_TRY(with_hasher(hash, [&](auto h) {
-        hipLaunchKernelGGL(merge_with_int_kernel<decltype(h)>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
+        typedef decltype(h) H;
+        if constexpr (H::COOP) {
+            if (count <= rcoop::COOP_MAX) {
+                rcoop::SeedWords sw;
+                memcpy(sw.w, seed.w, 32);
+                hipLaunchKernelGGL((rcoop::merge_with_int_kernel<typename H::Coop>), dim3((uint32_t)((count + 15) / 16)), dim3(256), 0,
+                                   ctx->stream, sw, first_value, count, (uint64_t *)d_out);
+                return (int)WF_OK;
+            }
+        }
+        hipLaunchKernelGGL(merge_with_int_kernel<H>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, seed, first_value, count, d_out);
         return (int)WF_OK;
     }));
     WF_HIP(hipGetLastError());

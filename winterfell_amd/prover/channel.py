@@ -51,8 +51,9 @@ class ProverChannel:
     # ---- public coin (channel.rs:112-165); linear batching: one draw per coefficient (air/src/air/coefficients.rs:201-206)
     def get_constraint_composition_coeffs(self):
         D = self.options.ext_degree
-        t = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_transition_constraints())])
-        b = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_assertions())])
+        self.public_coin.prefetch(self.air.num_transition_constraints() + self.air.num_assertions())
+        t = self.public_coin.draw_many(self.air.num_transition_constraints(), D)
+        b = self.public_coin.draw_many(self.air.num_assertions(), D)
         return ConstraintCompositionCoefficients(t, b)
 
     def get_ood_point(self):
@@ -60,8 +61,9 @@ class ProverChannel:
 
     def get_deep_composition_coeffs(self):
         D = self.options.ext_degree
-        trace = np.stack([self.public_coin.draw(D) for _ in range(self.air.TRACE_WIDTH)])
-        constraints = np.stack([self.public_coin.draw(D) for _ in range(self.air.num_constraint_composition_columns())])
+        self.public_coin.prefetch(self.air.TRACE_WIDTH + self.air.num_constraint_composition_columns())
+        trace = self.public_coin.draw_many(self.air.TRACE_WIDTH, D)
+        constraints = self.public_coin.draw_many(self.air.num_constraint_composition_columns(), D)
         return trace, constraints
 
     # ---- fri::ProverChannel (fri/src/prover/channel.rs:24-50)

@@ -114,10 +114,11 @@ class DeepCompositionPoly:
         self.coefficients, self.field, self.ctx = out, f, ctx
 
     def degree(self):
-        """polynom::degree_of: index of the highest non-zero coefficient."""
-        c = self.ctx.to_host(self.coefficients).reshape(self.poly_size(), -1)
-        nz = np.nonzero(c.any(axis=1))[0]
-        return int(nz[-1]) if len(nz) else 0
+        """polynom::degree_of: index of the highest non-zero coefficient (reduced on the device; one scalar comes back)."""
+        n = self.poly_size()
+        nz = (self.coefficients.reshape(n, -1) != 0).any(dim=1)
+        first_from_top = int(nz.flip(0).to(nz.device, dtype=self.coefficients.dtype).argmax())
+        return n - 1 - first_from_top if bool(nz[n - 1 - first_from_top]) else 0
 
     def evaluate(self, domain):
         """composer/mod.rs:174-181: evaluations over the LDE domain (device vector)."""
