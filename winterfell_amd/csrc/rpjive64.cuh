@@ -53,7 +53,7 @@ __device__ __forceinline__ void permute(uint64_t (&st)[8]) {
         mds(st);
 #pragma unroll
         for (int i = 0; i < 8; i++) st[i] = gl::add(st[i], ARK1_T.v[r][i]);
-        rp64::inv_sbox<8>(st);
+        rp64::inv_sbox_chunked<8>(st);
         mds(st);
 #pragma unroll
         for (int i = 0; i < 8; i++) st[i] = gl::add(st[i], ARK2_T.v[r][i]);
