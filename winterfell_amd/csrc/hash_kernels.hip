@@ -172,7 +172,8 @@ struct HRpJive {
 
 // Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs): four f62 words per digest, defined over f62 only
 struct HRp62 {
-    static constexpr bool COOP = false;
+    static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
+    typedef rcoop::CoopRp62 Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;
     static const char *row_name() { return "hash_rows_rp62"; }
     static const char *merkle_name() { return "merkle_stage_rp62"; }

@@ -1,4 +1,4 @@
-// Lane-cooperative Rescue-Prime permutations for SMALL batches (Rp64_256 width 12, RpJive64_256 width 8).
+// Lane-cooperative Rescue-Prime permutations for SMALL batches (Rp64_256 / Rp62_248 width 12, RpJive64_256 width 8).
 //
 // rp64.cuh / rpjive64.cuh keep one whole state per lane: best throughput, but a permutation is ~6400 dependent-ish
 // modmuls, i.e. ~0.2 ms of one wave no matter how few hashes are in flight.  The upper levels of every Merkle tree, the
@@ -13,6 +13,7 @@
 // LDS ordering: the 16 lanes of a group sit in one wavefront and a wavefront's DS instructions execute in issue order,
 // so a ds_write followed by ds_reads needs no barrier; `volatile` keeps the compiler from reordering or caching them.
 #pragma once
+#include "rp62.cuh"
 #include "rpjive64.cuh"
 
 namespace rcoop {
@@ -20,7 +21,18 @@ namespace rcoop {
 constexpr int GROUP = 16;               // lanes per state
 constexpr uint64_t COOP_MAX = 1u << 14;  // use the cooperative kernels up to this many hashes per launch
 
-struct Spec12 {                          // Rp64_256: crypto/src/hash/rescue/rp64_256/mod.rs:390 (MDS), :741 / :842 (ARK1 / ARK2)
+// S-boxes and additions shared by the two Goldilocks instances
+struct GlOps {
+    static __device__ __forceinline__ uint64_t fwd(uint64_t s) { return rp64::exp7(s); }
+    static __device__ __forceinline__ uint64_t inv(uint64_t s) {
+        uint64_t t[1] = {s};
+        rp64::inv_sbox<1>(t);
+        return t[0];
+    }
+    static __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) { return gl::add(a, b); }
+};
+
+struct Spec12 : GlOps {                  // Rp64_256: crypto/src/hash/rescue/rp64_256/mod.rs:390 (MDS), :741 / :842 (ARK1 / ARK2)
     static constexpr int W = 12;
     static __device__ __forceinline__ uint32_t row(int k) {
         constexpr uint32_t R[12] = {7, 23, 8, 26, 13, 10, 9, 7, 6, 22, 21, 8};
@@ -28,8 +40,9 @@ struct Spec12 {                          // Rp64_256: crypto/src/hash/rescue/rp6
     }
     static __device__ __forceinline__ uint64_t ark1(int r, int i) { return rp64::ARK1_T.v[r][i]; }
     static __device__ __forceinline__ uint64_t ark2(int r, int i) { return rp64::ARK2_T.v[r][i]; }
+    static __device__ __forceinline__ uint64_t mds(uint64_t s, int i, int ii, volatile uint64_t *grp);
 };
-struct Spec8 {                           // RpJive64_256: rp64_256_jive/mod.rs:417-499
+struct Spec8 : GlOps {                   // RpJive64_256: rp64_256_jive/mod.rs:417-499
     static constexpr int W = 8;
     static __device__ __forceinline__ uint32_t row(int k) {
         constexpr uint32_t R[8] = {23, 8, 13, 10, 7, 6, 21, 8};
@@ -37,6 +50,7 @@ struct Spec8 {                           // RpJive64_256: rp64_256_jive/mod.rs:4
     }
     static __device__ __forceinline__ uint64_t ark1(int r, int i) { return rpj::ARK1_T.v[r][i]; }
     static __device__ __forceinline__ uint64_t ark2(int r, int i) { return rpj::ARK2_T.v[r][i]; }
+    static __device__ __forceinline__ uint64_t mds(uint64_t s, int i, int ii, volatile uint64_t *grp);
 };
 
 // word `from` of the group's states, as seen after every lane published `s`
@@ -45,8 +59,9 @@ __device__ __forceinline__ uint64_t exchange(uint64_t s, int i, int from, volati
     return grp[from];
 }
 
+// circulant MDS with small entries: exact integer row sum on the 32-bit halves, reduced once (as rp64::mds / rpj::mds)
 template <class S>
-__device__ __forceinline__ uint64_t mds(uint64_t s, int i, int ii, volatile uint64_t *grp) {
+__device__ __forceinline__ uint64_t mds_small(uint64_t s, int i, int ii, volatile uint64_t *grp) {
     grp[i] = s;
     uint64_t al = 0, ah = 0;
 #pragma unroll
@@ -62,16 +77,38 @@ __device__ __forceinline__ uint64_t mds(uint64_t s, int i, int ii, volatile uint
     return gl::reduce160(low, (uint32_t)(ah >> 32) + carry, 0);
 }
 
+// Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs): f62 words in [0, 2M), x^3 / x^(1/3), dense 12 x 12 MDS applied in the
+// batched kernel's order (acc = m_0 x_0, then + m_j x_j), so the lazily reduced representatives agree word for word
+struct Spec62 {
+    static constexpr int W = 12;
+    static __device__ __forceinline__ uint64_t fwd(uint64_t s) { return f62::mul(f62::mul(s, s), s); }
+    static __device__ __forceinline__ uint64_t inv(uint64_t s) {
+        uint64_t t[1] = {s};
+        rp62::inv_sbox_w<1>(t);
+        return t[0];
+    }
+    static __device__ __forceinline__ uint64_t add(uint64_t a, uint64_t b) { return f62::add(a, b); }
+    static __device__ __forceinline__ uint64_t ark1(int r, int i) { return rp62::TBL.ark1[r][i]; }
+    static __device__ __forceinline__ uint64_t ark2(int r, int i) { return rp62::TBL.ark2[r][i]; }
+    static __device__ __forceinline__ uint64_t mds(uint64_t s, int i, int ii, volatile uint64_t *grp) {
+        grp[i] = s;
+        uint64_t acc = f62::mul(rp62::TBL.mds[ii][0], grp[0]);
+#pragma unroll
+        for (int j = 1; j < 12; j++) acc = f62::add(acc, f62::mul(rp62::TBL.mds[ii][j], grp[j]));
+        return acc;
+    }
+};
+
 // i = lane within the group, ii = min(i, W - 1) (idle lanes shadow the last word so that every address stays in range)
+__device__ __forceinline__ uint64_t Spec12::mds(uint64_t s, int i, int ii, volatile uint64_t *grp) { return mds_small<Spec12>(s, i, ii, grp); }
+__device__ __forceinline__ uint64_t Spec8::mds(uint64_t s, int i, int ii, volatile uint64_t *grp) { return mds_small<Spec8>(s, i, ii, grp); }
+
 template <class S>
 __device__ __forceinline__ uint64_t permute(uint64_t s, int i, int ii, volatile uint64_t *grp) {
 #pragma unroll 1
     for (int r = 0; r < 7; r++) {
-        s = rp64::exp7(s);
-        s = gl::add(mds<S>(s, i, ii, grp), S::ark1(r, ii));
-        uint64_t t[1] = {s};
-        rp64::inv_sbox<1>(t);
-        s = gl::add(mds<S>(t[0], i, ii, grp), S::ark2(r, ii));
+        s = S::add(S::mds(S::fwd(s), i, ii, grp), S::ark1(r, ii));
+        s = S::add(S::mds(S::inv(s), i, ii, grp), S::ark2(r, ii));
     }
     return s;
 }
@@ -157,6 +194,40 @@ struct CoopRpJive {
         if (i == 5 && big) s = rp64::mont_small(1);
         if (i == 7) s = rp64::mont_small(big ? 6 : 5);
         return jive(s, permute<S>(s, i, ii, grp), i, grp);
+    }
+    static __device__ __forceinline__ bool out_lane(int i) { return i < 4; }
+    static __device__ __forceinline__ int out_word(int i) { return i; }
+};
+
+// ---- Rp62_248 ---------------------------------------------------------------------------------------------------------
+struct CoopRp62 {
+    typedef Spec62 S;
+    // merge (rp62_248/mod.rs:155-170): the two digests in state[0..8], 8 in state[11]; digest = state[0..4]
+    static __device__ __forceinline__ uint64_t merge(const uint64_t *pair, int i, int ii, volatile uint64_t *grp) {
+        uint64_t s = 0;
+        if (i < 8) s = f62::norm(pair[i]);
+        if (i == 11) s = rp62::to_mont(8);
+        return permute<S>(s, i, ii, grp);
+    }
+    // hash_elements (mod.rs:203-236)
+    static __device__ __forceinline__ uint64_t hash_elements(const uint64_t *p, uint32_t n, int i, int ii, volatile uint64_t *grp) {
+        uint64_t s = i == 11 ? rp62::to_mont(n) : 0;
+        for (uint32_t base = 0; base < n; base += 8) {
+            const uint32_t idx = base + (uint32_t)i;
+            if (i < 8 && idx < n) s = f62::add(s, f62::norm(p[idx]));
+            s = permute<S>(s, i, ii, grp);
+        }
+        return s;
+    }
+    // merge_with_int (mod.rs:172-201)
+    static __device__ __forceinline__ uint64_t merge_with_int(const uint32_t (&seed)[8], uint64_t value, int i, int ii, volatile uint64_t *grp) {
+        const bool big = value >= f62::M;
+        uint64_t s = 0;
+        if (i < 4) s = f62::norm((uint64_t)seed[2 * i] | ((uint64_t)seed[2 * i + 1] << 32));
+        if (i == 4) s = rp62::to_mont(value % f62::M);
+        if (i == 5 && big) s = rp62::to_mont(value / f62::M);
+        if (i == 11) s = rp62::to_mont(big ? 6 : 5);
+        return permute<S>(s, i, ii, grp);
     }
     static __device__ __forceinline__ bool out_lane(int i) { return i < 4; }
     static __device__ __forceinline__ int out_word(int i) { return i; }

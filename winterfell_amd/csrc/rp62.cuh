@@ -26,41 +26,57 @@ constexpr Tables make_tables(const uint64_t (&mds)[12][12], const uint64_t (&a1)
 static __constant__ Tables TBL = make_tables(RP62_MDS, RP62_ARK1, RP62_ARK2);
 
 
-// acc = acc^(2^N) * tail for all 12 lanes (exp_acc, crypto/src/hash/rescue/mod.rs:20-28)
-template <int N>
-__device__ __forceinline__ void exp_acc(uint64_t (&acc)[12], const uint64_t (&tail)[12]) {
+// acc = acc^(2^N) * tail for W state words (exp_acc, crypto/src/hash/rescue/mod.rs:20-28)
+template <int N, int W>
+__device__ __forceinline__ void exp_acc(uint64_t (&acc)[W], const uint64_t (&tail)[W]) {
 #pragma unroll 1
     for (int k = 0; k < N; k++) {
 #pragma unroll
-        for (int i = 0; i < 12; i++) acc[i] = f62::mul(acc[i], acc[i]);
+        for (int i = 0; i < W; i++) acc[i] = f62::mul(acc[i], acc[i]);
     }
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = f62::mul(acc[i], tail[i]);
+    for (int i = 0; i < W; i++) acc[i] = f62::mul(acc[i], tail[i]);
 }
 
-// x^(1/3) = x^3074416663688030891, the 69-multiplication chain of mod.rs:291-318
-__device__ __forceinline__ void inv_sbox(uint64_t (&st)[12]) {
-    uint64_t t1[12], t2[12], t4[12], t8[12], acc[12];
+// x^(1/3) = x^3074416663688030891, the 69-multiplication chain of mod.rs:291-318, on W words
+template <int W>
+__device__ __forceinline__ void inv_sbox_w(uint64_t (&st)[W]) {
+    uint64_t t1[W], t2[W], t4[W], t8[W], acc[W];
 #pragma unroll
-    for (int i = 0; i < 12; i++) {
+    for (int i = 0; i < W; i++) {
         t1[i] = f62::mul(st[i], st[i]);    // x^10b
         t2[i] = t1[i];
     }
-    exp_acc<2>(t2, t1);                    // x^1010b
+    exp_acc<2, W>(t2, t1);                 // x^1010b
 #pragma unroll
-    for (int i = 0; i < 12; i++) t4[i] = t2[i];
-    exp_acc<4>(t4, t2);                    // x^10101010b
+    for (int i = 0; i < W; i++) t4[i] = t2[i];
+    exp_acc<4, W>(t4, t2);                 // x^10101010b
 #pragma unroll
-    for (int i = 0; i < 12; i++) t8[i] = t4[i];
-    exp_acc<8>(t8, t4);                    // x^1010101010101010b
+    for (int i = 0; i < W; i++) t8[i] = t4[i];
+    exp_acc<8, W>(t8, t4);                 // x^1010101010101010b
 #pragma unroll
-    for (int i = 0; i < 12; i++) acc[i] = t8[i];
-    exp_acc<7>(acc, t2);
-    exp_acc<15>(acc, t8);
-    exp_acc<16>(acc, t8);
-    exp_acc<8>(acc, t4);
+    for (int i = 0; i < W; i++) acc[i] = t8[i];
+    exp_acc<7, W>(acc, t2);
+    exp_acc<15, W>(acc, t8);
+    exp_acc<16, W>(acc, t8);
+    exp_acc<8, W>(acc, t4);
 #pragma unroll
-    for (int i = 0; i < 12; i++) st[i] = f62::mul(st[i], acc[i]);
+    for (int i = 0; i < W; i++) st[i] = f62::mul(st[i], acc[i]);
+}
+
+// all 12 words, 4 at a time in a real loop (register pressure: see rp64::inv_sbox_chunked)
+__device__ __forceinline__ void inv_sbox(uint64_t (&st)[12]) {
+    uint64_t h[4];
+#pragma unroll 1
+    for (int part = 0; part < 3; part++) {
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            if (i / 4 == part) h[i % 4] = st[i];
+        inv_sbox_w<4>(h);
+#pragma unroll
+        for (int i = 0; i < 12; i++)
+            if (i / 4 == part) st[i] = h[i % 4];
+    }
 }
 
 __device__ __forceinline__ void mds(uint64_t (&st)[12]) {
