@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--queries", type=int, default=28)
     ap.add_argument("--grinding", type=int, default=16)
     ap.add_argument("--repeat", type=int, default=3)
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel HIP-event totals of one more run")
     a = ap.parse_args()
     import winterfell_amd
     from winterfell_amd import air as wair, crypto, prover
@@ -64,10 +65,20 @@ def main():
         tm["total"] = (time.perf_counter() - t0) * 1e3
         if best is None or tm["total"] < best["total"]:
             best = tm
+    kernels = None
+    if a.kernels:
+        proof = None
+        ctx.prof_enable(True)
+        proof = prover.prove(air, prover.ColMatrix(trace, 1, ctx, f), options, hasher, [f.new(result)])
+        agg = ctx.prof_collect()
+        ctx.prof_enable(False)
+        kernels = {k: [c, round(ms, 3)] for k, (c, ms) in sorted(agg.items(), key=lambda kv: -kv[1][1])}
+        kernels["sum_ms"] = round(sum(ms for _, ms in agg.values()), 3)
     print(json.dumps({"example": "fib_small", "trace_length": n, "hash": a.hash, "ext_degree": a.ext, "blowup": a.blowup,
                       "build_trace_ms_host": round(t_trace, 2), "prove_ms": {k: round(v, 3) for k, v in best.items()},
                       "pow_nonce": int(proof.pow_nonce), "num_unique_queries": len(proof.query_positions),
-                      "fri_layers": len(proof.fri_layers), "trace_root": bytes(proof.trace_commitment).hex()}))
+                      "fri_layers": len(proof.fri_layers), "trace_root": bytes(proof.trace_commitment).hex(),
+                      **({"kernels": kernels} if kernels else {})}))
 
 
 if __name__ == "__main__":
