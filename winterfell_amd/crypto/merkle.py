@@ -126,7 +126,7 @@ class MerkleTree:
         return self._nodes_dev
 
     def num_leaves(self):
-        return self._leaves_dev.numel() // 32
+        return len(self._leaves) if self._leaves_dev is None else self._leaves_dev.numel() // 32
 
     def _fetch(self, which, idxs):
         """digests at the given positions of the leaf ('L') or node ('N') array: from the host copy when one exists,
