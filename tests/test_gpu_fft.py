@@ -159,3 +159,44 @@ def test_beyond_baseline_sizes(wf, oracle, log_n):
     vals = ctx.to_host(ea[torch.tensor(ks, device=ea.device)])
     for k, v in zip(ks, vals):
         assert int(v) == oracle.poly_eval(a, oracle.f64_exp(w, k)), k
+
+
+def test_concurrent_threads_with_their_own_contexts(oracle):
+    """SURVEY 8b threading convention: `ColMatrix::interpolate_columns` calls fft::interpolate_poly from many Rayon
+    threads at once (col_matrix.rs:194-199), and TraceLde must be Sync.  The library's rule is one context per calling
+    thread (include/winterfell_hip.h): four threads, each with its own context on its own stream, hammer different sizes
+    concurrently (ctypes drops the GIL during the calls); every result must still be the oracle's."""
+    import threading
+    import torch
+    from winterfell_amd import crypto, prover
+    from winterfell_amd._lib import Context
+    from winterfell_amd.math import fft, fields
+    cases = []
+    for t, log_n in enumerate((10, 13, 16, 12)):
+        p = oracle.f64_from_int(rand_field(900 + t, 1 << log_n))
+        cases.append((p, oracle.evaluate_poly(p, par=True), oracle.evaluate_poly_with_offset(p, oracle.f64_new(7), 8, par=True)))
+    errors = []
+
+    def worker(t):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                ctx = Context(0)
+                p, want_ev, want_lde = cases[t]
+                for it in range(12):
+                    got = fft.evaluate_poly(p.copy(), ctx=ctx)
+                    assert np.array_equal(got, want_ev), ("evaluate", t, it)
+                    assert np.array_equal(fft.interpolate_poly(got.copy(), ctx=ctx), p), ("interpolate", t, it)
+                    lde = fft.evaluate_poly_with_offset(p.copy(), None, fields.new(7), 8, ctx=ctx)
+                    assert np.array_equal(lde, want_lde), ("lde", t, it)
+                    tree = crypto.MerkleTree.new(crypto.Blake3_256, lde.view(np.uint8).reshape(-1, 32), ctx)
+                    assert np.array_equal(tree.root(), oracle.merkle_build(0, lde.view(np.uint8).reshape(-1, 32))[1]), ("merkle", t, it)
+                ctx.close()
+        except Exception as e:      # surfaced in the main thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(len(cases))]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
