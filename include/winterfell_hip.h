@@ -83,6 +83,12 @@ int wf_free(wf_ctx *ctx, void *d_ptr);
 int wf_memcpy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wf_memcpy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronises */
 int wf_memcpy_d2d(wf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);
+/* Page-lock a host buffer the caller owns (a Rust Vec's allocation: ColMatrix columns going in, RowMatrix / polys /
+ * nodes coming out) so that wf_memcpy_h2d / wf_memcpy_d2h move it by DMA at PCIe rate instead of staging pageable
+ * memory through the runtime's bounce buffers.  No reference counterpart (the reference never leaves the host);
+ * the shim registers a buffer once, before the copies, and unregisters it before the Vec is dropped. */
+int wf_host_register(wf_ctx *ctx, void *h_ptr, size_t bytes);
+int wf_host_unregister(wf_ctx *ctx, void *h_ptr);
 
 /* ---- math::fft ------------------------------------------------------------------------------------- */
 /* fft::get_twiddles / get_inv_twiddles (math/src/fft/mod.rs:455-505): n/2 elements, bit-reverse permuted. */

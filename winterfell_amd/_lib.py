@@ -31,6 +31,8 @@ _PROTOS = {
     "wf_memcpy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "wf_memcpy_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
     "wf_memcpy_d2d": [_vp, _vp, _vp, ctypes.c_size_t],
+    "wf_host_register": [_vp, _vp, ctypes.c_size_t],
+    "wf_host_unregister": [_vp, _vp],
     "wf_fft_get_twiddles": [_vp, _int, _u32, _int, _vp],
     "wf_fft_evaluate_poly": [_vp, _int, _u32, _vp, _u32, _u32],
     "wf_fft_interpolate_poly": [_vp, _int, _u32, _vp, _u32, _u32],

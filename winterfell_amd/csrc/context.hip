@@ -120,6 +120,18 @@ extern "C" int wf_memcpy_d2d(wf_ctx *ctx, void *d_dst, const void *d_src, size_t
     return WF_OK;
 }
 
+extern "C" int wf_host_register(wf_ctx *ctx, void *h_ptr, size_t bytes) {
+    if (!ctx || !h_ptr || bytes == 0) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return WF_OK;
+}
+
+extern "C" int wf_host_unregister(wf_ctx *ctx, void *h_ptr) {
+    if (!ctx || !h_ptr) return WF_ERR_INVALID_ARG;
+    WF_HIP(hipHostUnregister(h_ptr));
+    return WF_OK;
+}
+
 // ---- profiling hook ---------------------------------------------------------------------------------
 extern "C" int wf_prof_enable(wf_ctx *ctx, int on) {
     if (!ctx) return WF_ERR_INVALID_ARG;
