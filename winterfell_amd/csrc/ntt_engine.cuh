@@ -95,9 +95,24 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     constexpr int TC = 256 / B;         // tile columns
     constexpr int G = A / B;            // B-point DFTs per thread in step 2
     static_assert(B == 1 || G == 1 || G == 2, "A must be B or 2B");
-    // LDS exchange buffer: non-last [k_a][b][t] with padded k_a rows; last [k_a][t][b] with padded b rows
+    // LDS exchange buffer: non-last [k_a][b][t], last [k_a][t][b].  Bank conflicts are avoided by XOR-swizzling the index
+    // inside a row instead of padding the rows: a radix-256 tile of 64-bit elements is then exactly 32 KiB, so FIVE
+    // workgroups fit the CU's 160 KiB (padded rows: 34 KiB, four) — one more wave per SIMD for a VALU-bound kernel.
+    //   non-last: rows of 256 elements; odd k_a rows have bit 4 of the column flipped (= a 16-element shift, what the
+    //             padding did modulo the bank count): writes stay lane-linear, reads at fixed b spread over k_a parity
+    //   last:     rows of B elements; b is XORed with (t ^ k_a) so that lanes that differ in t (stride B elements = the
+    //             same banks) or in k_a land on different banks
+#ifdef NTT_LDS_PADDED
     constexpr int ROW_NL = B * TC + 16;
     constexpr int ROW_L = B + 1;
+    auto idx_nl = [](int ka, int col) -> int { return ka * ROW_NL + col; };
+    auto idx_l = [](int ka, int t, int b) -> int { return (ka * TC + t) * ROW_L + b; };
+#else
+    constexpr int ROW_NL = B * TC;
+    constexpr int ROW_L = B;
+    auto idx_nl = [](int ka, int col) -> int { return ka * ROW_NL + (col ^ ((ka & 1) << 4)); };
+    auto idx_l = [](int ka, int t, int b) -> int { return (ka * TC + t) * ROW_L + (b ^ ((t ^ ka) & (B - 1))); };
+#endif
     constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * TC * ROW_L : A * ROW_NL);
     __shared__ T lds[LDS_ELEMS];
 
@@ -194,8 +209,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 const int ka = brev(i, LOG_A);
                 T val = x[i];
                 if (ka != 0 || (LAST && p.scale_in_w256)) val = F::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
-                if (!LAST) lds[ka * ROW_NL + b1 * TC + t1] = val;
-                else lds[(ka * TC + t1) * ROW_L + b1] = val;
+                if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
+                else lds[idx_l(ka, t1, b1)] = val;
             }
         }
     }
@@ -272,8 +287,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
             T y[B];
 #pragma unroll
             for (int bb = 0; bb < B; bb++) {
-                if (!LAST) y[bb] = lds[ka * ROW_NL + bb * TC + t2];
-                else y[bb] = lds[(ka * TC + t2) * ROW_L + bb];
+                if (!LAST) y[bb] = lds[idx_nl(ka, bb * TC + t2)];
+                else y[bb] = lds[idx_l(ka, t2, bb)];
             }
             dft_dif<F, LOG_B>(y, p.w16);
             if constexpr (!LAST) {
