@@ -129,6 +129,19 @@ int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const vo
                            uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
                            void *d_lde);
 
+/* ColMatrix::evaluate_columns_over (col_matrix.rs:230-243; the column-major LDE the reference's benches/row_matrix.rs
+ * compares RowMatrix against): column k of d_out (at k * out_col_stride base elements) = fft::evaluate_poly_with_offset
+ * of column k of d_polys; natural order, (n << log_blowup) elements each. */
+int wf_evaluate_columns_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
+                             uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, void *d_out,
+                             uint64_t out_col_stride);
+
+/* ColMatrix::commit_to_rows, row-hash part (col_matrix.rs:262-286): leaf[r] = H::hash_elements([col_0[r], col_1[r], ...])
+ * for a COLUMN-major matrix (column k at d_cols + k * col_stride base elements, num_rows elements of ext_degree words).
+ * No partitions (the reference's ColMatrix has none).  Feed d_leaves to wf_merkle_build for the commitment. */
+int wf_hash_columns(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_cols, uint32_t num_cols,
+                    uint64_t col_stride, uint64_t num_rows, void *d_leaves);
+
 /* RowMatrix::commit_to_rows, row-hash part (row_matrix.rs:184-228) with PartitionOptions
  * (air/src/options.rs:428-444): leaf[r] = H::hash_elements(row r) or, when partitioned,
  * H::merge_many(H::hash_elements(chunk_k)).  A row is its first elems_per_row base elements. */

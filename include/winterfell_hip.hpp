@@ -243,6 +243,21 @@ struct ColMatrix {
               "wf_interpolate_columns");
         return out;
     }
+    // ColMatrix::evaluate_columns_over (col_matrix.rs:230-243): column-major coset LDE
+    ColMatrix evaluate_columns_over(uint64_t blowup, const uint64_t *domain_offset) const {
+        Context &ctx = data.ctx();
+        ColMatrix out{DeviceBuffer(ctx, num_cols * num_rows * blowup * ext_degree * 8 * words(field)), field, num_cols, ext_degree, num_rows * blowup};
+        check(wf_evaluate_columns_over(ctx.handle(), (int)field, ext_degree, data.data(), num_cols, col_stride(), log2_exact(num_rows, "rows"),
+                                       log2_exact(blowup, "blowup factor"), domain_offset, out.data.data(), out.col_stride()), "wf_evaluate_columns_over");
+        return out;
+    }
+    // ColMatrix::commit_to_rows (col_matrix.rs:262-286)
+    MerkleTree commit_to_rows(Hash h) const {
+        Context &ctx = data.ctx();
+        DeviceBuffer leaves(ctx, num_rows * 32);
+        check(wf_hash_columns(ctx.handle(), (int)h, (int)field, ext_degree, data.data(), num_cols, col_stride(), num_rows, leaves.data()), "wf_hash_columns");
+        return MerkleTree(h, std::move(leaves), num_rows);
+    }
 };
 
 // RowMatrix (row_matrix.rs:28-41): data[row * row_width + col], row_width = 8 * ceil(base columns / 8)

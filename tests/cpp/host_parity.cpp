@@ -131,6 +131,15 @@ int main() {
         wf::RowMatrix lde2 = wf::RowMatrix::evaluate_polys_over(tc.polys, blowup, &offset);
         wf::MerkleTree t2 = lde2.commit_to_rows((wf::Hash)hasher, wf::PartitionOptions{(uint32_t)parts, 1});
         EXPECT(t2.nodes() == o_nodes, "RowMatrix::commit_to_rows");
+        // column-major path of the reference's benches/row_matrix.rs: ColMatrix::evaluate_columns_over holds the same values
+        // as the row-major LDE, and with one partition ColMatrix::commit_to_rows commits to the same rows
+        wf::ColMatrix ev = tc.polys.evaluate_columns_over(blowup, &offset);
+        std::vector<uint64_t> evh = ev.data.to_host<uint64_t>();
+        bool same = ev.num_rows == N;
+        for (uint64_t r = 0; r < N && same; r += 37)
+            for (uint64_t k = 0; k < c; k++) same = same && evh[k * N + r] == o_lde[r * rw + k];
+        EXPECT(same, "ColMatrix::evaluate_columns_over == transposed RowMatrix");
+        if (parts == 1) EXPECT(ev.commit_to_rows((wf::Hash)hasher).nodes() == o_nodes, "ColMatrix::commit_to_rows");
     }
     {
         bool threw = false;

@@ -287,3 +287,51 @@ def test_strided_sharding_emulation_equals_default_commitment(wf, oracle, world,
         assert np.array_equal(ctx.to_host(res["shards"][k][1].data), o[1][k::world])
     full = parallel.assemble_nodes(world, N, [ctx.to_host(nd) for _, nd in res["per_rank"]], ctx.to_host(res["top"]))
     assert np.array_equal(full, o[3])
+
+
+@pytest.mark.parametrize("hname,c,log_n,D", [("Blake3_256", 3, 9, 1), ("Rp64_256", 5, 6, 1), ("Blake3_256", 2, 7, 2), ("Blake3_256", 70, 10, 1),
+                                               ("Sha3_256", 9, 1, 3), ("Blake3_256", 1, 12, 1)])
+def test_colmatrix_evaluate_columns_over_and_commit_to_rows(wf, oracle, hname, c, log_n, D):
+    """ColMatrix::evaluate_columns_over (col_matrix.rs:230-243) = fft::evaluate_poly_with_offset per column, and
+    ColMatrix::commit_to_rows (col_matrix.rs:262-286) = tree over hash_elements(row) of a COLUMN-major matrix."""
+    ctx, crypto, prover, fields = wf
+    hasher = getattr(crypto, hname)
+    hid = {"Blake3_256": 0, "Rp64_256": 1, "Sha3_256": 2}[hname]
+    n, blowup = 1 << log_n, 4
+    cols = np.stack([oracle.f64_from_int(rand_field(31 * c + k, n * D)) for k in range(c)])
+    m = prover.ColMatrix(cols.copy(), D, ctx)
+    dom = prover.StarkDomain(n, blowup)
+    ev = m.evaluate_columns_over(dom)
+    assert ev.num_cols() == c and ev.num_rows() == n * blowup and ev.ext_degree == D
+    got = ev.to_host()
+    for k in range(c):
+        assert np.array_equal(got[k], oracle.evaluate_poly_with_offset(cols[k], oracle.f64_new(7), blowup, D=D)), k
+    # row hashes of the column-major matrix: row r = [col_0[r], col_1[r], ...] (D words each)
+    tree = m.commit_to_rows(hasher)
+    rows = cols.reshape(c, n, D).transpose(1, 0, 2).reshape(n, c * D)
+    want_leaves = np.stack([oracle.hash_elements(hid, rows[r]) for r in range(n)])
+    assert np.array_equal(tree.leaves, want_leaves)
+    assert np.array_equal(tree.root(), oracle.merkle_build(hid, want_leaves)[1])
+    # accessors (col_matrix.rs:85-165)
+    assert np.array_equal(m.get(c - 1, n - 1), cols[c - 1][(n - 1) * D:])
+    assert np.array_equal(m.read_row_into(1), rows[1])
+    extra = oracle.f64_from_int(rand_field(5, n * D))
+    m.merge_column(extra)
+    assert m.num_cols() == c + 1 and np.array_equal(m.get_column(c), extra)
+    assert np.array_equal(ctx.to_host(m.remove_column(0)), cols[0]) and m.num_cols() == c
+
+
+def test_colmatrix_commit_to_rows_f128(wf, oracle):
+    ctx, crypto, prover, fields = wf
+    f, of = fields.f128, oracle.f128
+    n, c = 1 << 8, 6
+    rng = np.random.default_rng(77)
+    cols = np.stack([f.pack([int(v) for v in rng.integers(0, 1 << 62, n)]) for _ in range(c)])    # small canonical values
+    m = prover.ColMatrix(cols.copy(), 1, ctx, f)
+    tree = m.commit_to_rows(crypto.Blake3_256)
+    rows = cols.reshape(c, n, 2).transpose(1, 0, 2).reshape(n, c * 2)
+    want = np.stack([np.frombuffer(oracle.blake3(rows[r].tobytes()), dtype=np.uint8) for r in range(n)])
+    assert np.array_equal(tree.leaves, want)
+    ev = m.evaluate_columns_over(prover.StarkDomain(n, 2, field=f)).to_host()
+    for k in range(c):
+        assert np.array_equal(ev[k], of.evaluate_poly_with_offset(cols[k], int(f.GENERATOR), 2))

@@ -40,6 +40,8 @@ _PROTOS = {
     "wf_fft_interpolate_poly_with_offset": [_vp, _int, _u32, _vp, _u32, _vp],
     "wf_interpolate_columns": [_vp, _int, _u32, _vp, _u32, _u64, _u32],
     "wf_evaluate_polys_over": [_vp, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _vp],
+    "wf_evaluate_columns_over": [_vp, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _u64],
+    "wf_hash_columns": [_vp, _int, _int, _u32, _vp, _u32, _u64, _u64, _vp],
     "wf_hash_rows": [_vp, _int, _int, _u32, _vp, _u64, _u64, _u32, _u32, _u32, _vp],
     "wf_merkle_build": [_vp, _int, _vp, _u64, _vp],
     "wf_hash_merge_batch": [_vp, _int, _vp, _u64, _vp],

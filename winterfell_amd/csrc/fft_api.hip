@@ -295,3 +295,19 @@ extern "C" int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degre
     if (!ctx || !d_polys || !d_lde || num_cols == 0 || log_n == 0) return WF_ERR_INVALID_ARG;
     WF_DISPATCH_FIELD(field, evaluate_polys_over, ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde);
 }
+
+extern "C" int wf_evaluate_columns_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
+                                        uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, void *d_out,
+                                        uint64_t out_col_stride) {
+    if (!ctx || !d_polys || !d_out || num_cols == 0 || log_n == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
+    if (col_stride < ((uint64_t)ext_degree << log_n) || out_col_stride < ((uint64_t)ext_degree << (log_n + log_blowup)))
+        return WF_ERR_INVALID_ARG;
+    const size_t es = field == WF_FIELD_F128 ? 16 : 8;
+    // one coset evaluation per column (each already a batch of ext_degree * blowup size-n transforms)
+    for (uint32_t k = 0; k < num_cols; k++) {
+        const void *src = (const uint8_t *)d_polys + (size_t)k * col_stride * es;
+        void *dst = (uint8_t *)d_out + (size_t)k * out_col_stride * es;
+        WF_TRY(wf_fft_evaluate_poly_with_offset(ctx, field, ext_degree, src, log_n, h_offset, log_blowup, dst));
+    }
+    return WF_OK;
+}

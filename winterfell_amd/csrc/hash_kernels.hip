@@ -453,6 +453,26 @@ __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint
     reinterpret_cast<uint64_t *>(out)[gid] = reinterpret_cast<const uint64_t *>(rows + pos[r] * row_bytes)[w];
 }
 
+// rows[r][c * W + w] = cols[c * col_words + r * W + w]  (W = 64-bit words per matrix element): column-major -> row-major
+// through an LDS tile of R rows so that both the column reads (R * W consecutive words) and the row writes are coalesced
+__global__ __launch_bounds__(256) void cols_to_rows_kernel(const uint64_t *cols, uint64_t col_words, uint32_t num_cols, uint32_t W,
+                                                           uint64_t num_rows, uint32_t R, uint64_t *rows) {
+    extern __shared__ uint64_t tile[];                 // [R][num_cols * W + 1]
+    const uint32_t rw = num_cols * W, pitch = rw + 1;
+    const uint64_t r0 = (uint64_t)blockIdx.x * R;
+    const uint32_t nr = num_rows - r0 < R ? (uint32_t)(num_rows - r0) : R;
+    const uint32_t run = nr * W;                       // consecutive words of one column in this tile
+    for (uint32_t idx = threadIdx.x; idx < num_cols * run; idx += 256) {
+        const uint32_t c = idx / run, k = idx % run;
+        tile[(k / W) * pitch + c * W + (k % W)] = cols[(uint64_t)c * col_words + r0 * W + k];
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < nr * rw; idx += 256) {
+        const uint32_t r = idx / rw, j = idx % rw;
+        rows[(r0 + r) * rw + j] = tile[r * pitch + j];
+    }
+}
+
 template <class H, int MODE, bool MULTI>
 int launch_hash_rows_t(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
                        uint32_t part_elems, uint32_t parts, void *out) {
@@ -635,6 +655,31 @@ extern "C" int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degre
                             void *d_leaves) {
     return hash_rows_impl(ctx, hash, field, ext_degree, d_rows, num_rows, row_width, elems_per_row, num_partitions,
                           hash_rate, d_leaves);
+}
+
+extern "C" int wf_hash_columns(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_cols, uint32_t num_cols,
+                               uint64_t col_stride, uint64_t num_rows, void *d_leaves) {
+    if (!ctx || !d_cols || !d_leaves || num_cols == 0 || num_rows == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
+    if (col_stride < num_rows * ext_degree) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    const uint32_t fw = field == WF_FIELD_F128 ? 2 : 1;          // 64-bit words per base element
+    const uint32_t W = ext_degree * fw;
+    const uint64_t rw = (uint64_t)num_cols * W;
+    if (rw > 4095) return WF_ERR_UNSUPPORTED;                    // one row must fit the LDS tile
+    uint32_t R = (uint32_t)(4096 / (rw + 1));                   // <= 32 KiB of LDS
+    if (R > 256) R = 256;
+    if (R == 0) R = 1;
+    void *tmp;
+    WF_TRY(wf_scratch(ctx, 1, (size_t)num_rows * rw * 8, &tmp));
+    const uint64_t blocks = (num_rows + R - 1) / R;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    wf_prof_begin(ctx, "cols_to_rows");
+    hipLaunchKernelGGL(cols_to_rows_kernel, dim3((uint32_t)blocks), dim3(256), (size_t)R * (rw + 1) * 8, ctx->stream, (const uint64_t *)d_cols,
+                       col_stride * fw, num_cols, W, num_rows, R, (uint64_t *)tmp);
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    const uint32_t bc = num_cols * ext_degree;                   // base elements per row
+    return hash_rows_impl(ctx, hash, field, ext_degree, tmp, num_rows, bc, bc, 1, 1, d_leaves);
 }
 
 extern "C" int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,

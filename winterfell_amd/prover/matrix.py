@@ -59,8 +59,61 @@ class ColMatrix:
         self.ctx.call("wf_interpolate_columns", self.field.ID, self.ext_degree, ptr(out), self.num_cols(), self.col_stride(), log_n)
         return ColMatrix(out, self.ext_degree, self.ctx, self.field)
 
+    def evaluate_columns_over(self, domain):
+        """ColMatrix::evaluate_columns_over (col_matrix.rs:230-243): the polynomials in the columns evaluated over the LDE
+        coset, column-major (the layout benches/row_matrix.rs compares RowMatrix against)."""
+        f, D = self.field, self.ext_degree
+        n, b = self.num_rows(), domain.trace_to_lde_blowup()
+        assert n == domain.trace_length
+        out = self.ctx.empty_u64(self.num_cols(), n * b * D * f.W)
+        off = f.element_words(int(domain.offset))
+        self.ctx.call("wf_evaluate_columns_over", f.ID, D, ptr(self.data), self.num_cols(), self.col_stride(), n.bit_length() - 1,
+                      b.bit_length() - 1, off.ctypes.data_as(ctypes.c_void_p), ptr(out), n * b * D)
+        return ColMatrix(out, D, self.ctx, f)
+
+    def hash_rows(self, hasher):
+        leaves = self.ctx.empty_u8(self.num_rows(), 32)
+        self.ctx.call("wf_hash_columns", hasher.HASH_ID, self.field.ID, self.ext_degree, ptr(self.data), self.num_cols(), self.col_stride(),
+                      self.num_rows(), ptr(leaves))
+        return leaves
+
+    def commit_to_rows(self, hasher):
+        """ColMatrix::commit_to_rows (col_matrix.rs:262-286): leaf r = hash_elements(row r), then the vector commitment."""
+        return MerkleTree.new(hasher, self.hash_rows(hasher), self.ctx)
+
+    # ---- element access (col_matrix.rs:85-165); host round trips, for tests and small fix-ups
+    def get(self, col_idx, row_idx):
+        assert col_idx < self.num_cols() and row_idx < self.num_rows()
+        w = self.ext_degree * self.field.W
+        return self.ctx.to_host(self.data[col_idx, row_idx * w:(row_idx + 1) * w])
+
+    def get_column(self, col_idx):
+        return self.ctx.to_host(self.data[col_idx])
+
+    def read_row_into(self, row_idx):
+        assert row_idx < self.num_rows()
+        w = self.ext_degree * self.field.W
+        return self.ctx.to_host(self.data[:, row_idx * w:(row_idx + 1) * w]).reshape(-1)
+
+    def merge_column(self, column):
+        """col_matrix.rs:150-155: append a column (its length must match)."""
+        col = self.ctx.to_device(np.ascontiguousarray(column, dtype=np.uint64).reshape(1, -1)) if isinstance(column, np.ndarray) else column.reshape(1, -1)
+        assert col.shape[1] == self.data.shape[1], "column length must match the matrix"
+        self.data = _cat([self.data, col])
+
+    def remove_column(self, index):
+        assert index < self.num_cols(), "column index out of range"
+        col = self.data[index].clone()
+        self.data = _cat([self.data[:index], self.data[index + 1:]])
+        return col
+
     def to_host(self):
         return self.ctx.to_host(self.data)
+
+
+def _cat(parts):
+    import torch
+    return torch.cat(parts, dim=0).contiguous()
 
 
 class RowMatrix:
