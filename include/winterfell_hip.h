@@ -112,6 +112,14 @@ int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree
 int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
                                         const void *h_offset);
 
+/* math::get_power_series_with_offset (math/src/utils/mod.rs:69-79; get_power_series is s = ONE): d_out[i] = s * b^i,
+ * i < n, base-field elements.  h_b / h_s: one element each, internal form. */
+int wf_get_power_series_with_offset(wf_ctx *ctx, int field, const void *h_b, const void *h_s, uint64_t n, void *d_out);
+
+/* math::batch_inversion (math/src/utils/mod.rs:169-215): d_out[i] = d_values[i]^-1, zero where d_values[i] is zero
+ * (serial_batch_inversion's rule).  Base-field elements; d_out may alias d_values. */
+int wf_batch_inversion(wf_ctx *ctx, int field, const void *d_values, uint64_t n, void *d_out);
+
 /* ---- prover::matrix -------------------------------------------------------------------------------- */
 /* ColMatrix::interpolate_columns (prover/src/matrix/col_matrix.rs:192-202): `num_cols` columns of n elements,
  * column k at d_cols + k * col_stride elements (col_stride >= n*ext_degree, in base elements); in place. */

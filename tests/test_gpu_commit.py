@@ -312,6 +312,8 @@ def test_colmatrix_evaluate_columns_over_and_commit_to_rows(wf, oracle, hname, c
     want_leaves = np.stack([oracle.hash_elements(hid, rows[r]) for r in range(n)])
     assert np.array_equal(tree.leaves, want_leaves)
     assert np.array_equal(tree.root(), oracle.merkle_build(hid, want_leaves)[1])
+    rm = prover.RowMatrix.evaluate_polys(m, blowup)                      # row_matrix.rs:57-74: offset = GENERATOR = 7
+    assert np.array_equal(rm.get(c - 1, 5), got[c - 1][5 * D:6 * D]) and np.array_equal(rm.row(3)[:D], got[0][3 * D:4 * D])
     # accessors (col_matrix.rs:85-165)
     assert np.array_equal(m.get(c - 1, n - 1), cols[c - 1][(n - 1) * D:])
     assert np.array_equal(m.read_row_into(1), rows[1])

@@ -225,3 +225,55 @@ def test_registered_host_buffers_round_trip(wf, oracle):
     from winterfell_amd._lib import WfError
     with pytest.raises(WfError):
         ctx.call("wf_host_register", None, 16)
+
+
+def test_serial_fft_permute_index_infer_degree(wf, oracle):
+    """the rest of math::fft's public surface: serial_fft (mod.rs:405-429), permute_index (:570-578), infer_degree
+    (:543-562, the doc example and a random polynomial of known degree)."""
+    ctx, fft, fields = wf
+    n = 1 << 9
+    p = oracle.f64_from_int(rand_field(808, n))
+    assert np.array_equal(fft.serial_fft(p.copy(), fft.get_twiddles(n)), oracle.evaluate_poly(p))
+    with pytest.raises(AssertionError):
+        fft.serial_fft(p.copy(), fft.get_twiddles(n // 2))
+    assert [fft.permute_index(8, i) for i in range(8)] == [0, 4, 2, 6, 1, 5, 3, 7] and fft.permute_index(1, 0) == 0
+    tw = ctx.to_host(fft.get_twiddles(16))
+    root = pow(fields.f64.get_root_of_unity(4), 1, fields.M)
+    assert all(int(fields.to_ints(tw)[fft.permute_index(8, i)]) == pow(root, i, fields.M) for i in range(8))      # mod.rs:464-467
+    # doc example: p(x) = x^2 + 1 over the coset of size 4 has degree 2
+    ev = oracle.evaluate_poly_with_offset(fields.from_ints([1, 0, 1, 0]), oracle.f64_new(7), 1)
+    assert fft.infer_degree(ev, fields.new(7)) == 2
+    for deg, D in ((100, 1), (37, 2), (0, 1)):
+        coeffs = np.zeros(256 * D, dtype=np.uint64)
+        coeffs[:(deg + 1) * D] = oracle.f64_from_int(rand_field(deg + 3, (deg + 1) * D) | np.uint64(1))
+        ev = oracle.evaluate_poly_with_offset(coeffs, oracle.f64_new(7), 4, D=D)
+        assert fft.infer_degree(ev, fields.new(7), ext_degree=D) == deg
+    with pytest.raises(AssertionError):
+        fft.infer_degree(ev, 0)
+
+
+@pytest.mark.parametrize("fname", ["f64", "f128", "f62"])
+def test_power_series_and_batch_inversion(wf, fname):
+    """math::utils (utils/mod.rs:36-79, 169-215) against python big-int arithmetic: s * b^i for ragged lengths, inverses with
+    zeros in the input staying zero."""
+    ctx, fft, fields = wf
+    from winterfell_amd.math import utils
+    f = getattr(fields, fname)
+    b, s = 3, 0x123456789ABCDEF % f.M
+    for n in (0, 1, 5, 16, 17, 1000, (1 << 16) + 3):
+        got = f.to_ints(ctx.to_host(utils.get_power_series_with_offset(f.new(b), f.new(s), n, field=f)))
+        want, cur = [], s
+        for _ in range(min(n, 1000)):
+            want.append(cur)
+            cur = cur * b % f.M
+        assert got[:len(want)] == want, n
+        if n > 1000:
+            assert got[n - 1] == s * pow(b, n - 1, f.M) % f.M
+    assert f.to_ints(ctx.to_host(utils.get_power_series(f.new(b), 4, field=f))) == [1, 3, 9, 27]
+    rng = np.random.default_rng(5)
+    vals = [int(v) % f.M for v in rng.integers(1, 1 << 62, 1003)]
+    for z in (0, 15, 16, 500, 1002):
+        vals[z] = 0
+    vals[1] = f.M - 1
+    got = f.to_ints(utils.batch_inversion(f.from_ints(vals), field=f))
+    assert got == [pow(v, f.M - 2, f.M) if v else 0 for v in vals]

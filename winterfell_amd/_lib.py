@@ -38,6 +38,8 @@ _PROTOS = {
     "wf_fft_interpolate_poly": [_vp, _int, _u32, _vp, _u32, _u32],
     "wf_fft_evaluate_poly_with_offset": [_vp, _int, _u32, _vp, _u32, _vp, _u32, _vp],
     "wf_fft_interpolate_poly_with_offset": [_vp, _int, _u32, _vp, _u32, _vp],
+    "wf_get_power_series_with_offset": [_vp, _int, _vp, _vp, _u64, _vp],
+    "wf_batch_inversion": [_vp, _int, _vp, _u64, _vp],
     "wf_interpolate_columns": [_vp, _int, _u32, _vp, _u32, _u64, _u32],
     "wf_evaluate_polys_over": [_vp, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _vp],
     "wf_evaluate_columns_over": [_vp, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _vp, _u64],

@@ -1,2 +1,2 @@
 """Mirror of the reference's `math` crate surface on the hot path (fields' internal forms + fft)."""
-from . import fft, fields  # noqa: F401
+from . import fft, fields, utils  # noqa: F401

@@ -115,3 +115,40 @@ def interpolate_poly_with_offset(evaluations, inv_twiddles, domain_offset, ext_d
         evaluations[...] = ctx.to_host(d).reshape(evaluations.shape)
         return evaluations
     return d
+
+
+def serial_fft(values, twiddles, ext_degree=1, ctx=None, field=fields.f64):
+    """fft::serial_fft (mod.rs:405-429): `fft_in_place` followed by `permute`, i.e. natural order in, natural order out —
+    the same transform as evaluate_poly, with its own argument checks (the twiddles are mandatory here)."""
+    n = (values.size if _is_np(values) else values.numel()) // (ext_degree * field.W)
+    if n == 0 or n & (n - 1):
+        raise AssertionError("number of values must be a power of 2, but was %d" % n)
+    nt = (twiddles.size if _is_np(twiddles) else twiddles.numel()) // field.W
+    if nt * 2 != n:
+        raise AssertionError("invalid number of twiddles: expected %d but received %d" % (n // 2, nt))
+    return _inplace("wf_fft_evaluate_poly", values, ext_degree, ctx, 1, field)
+
+
+def permute_index(size, index):
+    """fft::permute_index (mod.rs:570-578): bit reversal of `index` in a domain of `size` (a power of two)."""
+    assert size & (size - 1) == 0 and index < size
+    bits = size.bit_length() - 1
+    return int(format(index, "0%db" % bits)[::-1], 2) if bits else 0
+
+
+def infer_degree(evaluations, domain_offset, ext_degree=1, ctx=None, field=fields.f64):
+    """fft::infer_degree (mod.rs:543-562): interpolate over the coset and return the index of the highest non-zero
+    coefficient (polynom::degree_of); the reduction runs on the device."""
+    ctx = ctx or default_context()
+    n = (evaluations.size if _is_np(evaluations) else evaluations.numel()) // (ext_degree * field.W)
+    if n == 0 or n & (n - 1):
+        raise AssertionError("number of evaluations must be a power of 2")
+    if n.bit_length() - 1 > field.TWO_ADICITY:
+        raise AssertionError("multiplicative subgroup of size %d does not exist in the specified base field" % n)
+    if domain_offset == 0:
+        raise AssertionError("domain offset cannot be zero")
+    d = ctx.to_device(evaluations) if _is_np(evaluations) else evaluations.clone()
+    coeffs = interpolate_poly_with_offset(d, None, domain_offset, ext_degree=ext_degree, ctx=ctx, field=field)
+    nz = (coeffs.reshape(n, -1) != 0).any(dim=1)
+    top = int(nz.flip(0).to(dtype=coeffs.dtype).argmax())
+    return n - 1 - top if bool(nz[n - 1 - top]) else 0

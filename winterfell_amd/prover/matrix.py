@@ -139,11 +139,22 @@ class RowMatrix:
                  log_n, log_b, off.ctypes.data_as(ctypes.c_void_p), ptr(out))
         return cls(out, rw, polys.num_base_cols(), polys.ext_degree, ctx, f)
 
+    @classmethod
+    def evaluate_polys(cls, polys: ColMatrix, blowup_factor):
+        """RowMatrix::evaluate_polys (row_matrix.rs:57-74): the same over the coset with offset B::GENERATOR."""
+        return cls.evaluate_polys_over(polys, blowup_factor, polys.field.new(polys.field.GENERATOR))
+
     def num_rows(self):
         return self.data.shape[0]
 
     def num_cols(self):
         return self.elements_per_row // self.ext_degree
+
+    def get(self, col_idx, row_idx):
+        """row_matrix.rs:154-158"""
+        w = self.ext_degree * self.field.W
+        assert col_idx < self.num_cols() and row_idx < self.num_rows()
+        return self.ctx.to_host(self.data[row_idx, col_idx * w:(col_idx + 1) * w])
 
     def row(self, idx):
         assert idx < self.num_rows()
