@@ -337,3 +337,23 @@ def test_colmatrix_commit_to_rows_f128(wf, oracle):
     ev = m.evaluate_columns_over(prover.StarkDomain(n, 2, field=f)).to_host()
     for k in range(c):
         assert np.array_equal(ev[k], of.evaluate_poly_with_offset(cols[k], int(f.GENERATOR), 2))
+
+
+@pytest.mark.parametrize("hname,hid", [("Blake3_256", 0), ("Rp64_256", 1), ("Sha3_256", 2), ("RpJive64_256", 3), ("Blake3_192", 5)])
+def test_merge_many_on_every_hasher(wf, oracle, hname, hid):
+    """Hasher::merge_many (crypto/src/hash/mod.rs:39-41): single and batched calls vs the oracle; merge == merge_many for two
+    digests wherever the reference's tests say so (blake/tests.rs, rescue tests merge_vs_merge_many — not the Jive hasher,
+    whose merge is the compression mode)."""
+    ctx, crypto, prover, fields = wf
+    hasher = getattr(crypto, hname)
+    rng = np.random.default_rng(hid)
+    elems = oracle.f64_from_int(rand_field(60 + hid, 5 * 3 * 4)).reshape(5, 3, 4)
+    digs = np.ascontiguousarray(elems).view(np.uint8).reshape(5, 3, 32).copy()
+    if hname == "Blake3_192":
+        digs[:, :, 24:] = 0
+    got = hasher.merge_many(digs)
+    for i in range(5):
+        assert np.array_equal(got[i], oracle.merge_many(hid, digs[i])), i
+        assert np.array_equal(hasher.merge_many(digs[i]), got[i])
+    if hname != "RpJive64_256":
+        assert np.array_equal(hasher.merge_many(digs[0][:2]), hasher.merge(digs[0][:2]))

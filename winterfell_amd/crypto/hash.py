@@ -49,6 +49,21 @@ class _Hasher:
 
 
     @classmethod
+    def merge_many(cls, values, ctx=None):
+        """Hasher::merge_many(&[Digest]) (crypto/src/hash/mod.rs:39-41) — values: (k, 32) digests -> (32,), or (n, k, 32)
+        for n independent merges -> (n, 32).  Byte hashers hash the concatenated digest bytes (24 per digest for
+        Blake3_192); the Rescue hashers hash the digests' elements (overridden below with the same library call)."""
+        ctx = ctx or default_context()
+        v = np.ascontiguousarray(values).view(np.uint8)
+        single = v.ndim == 2
+        batch = v.reshape(1, -1, 32) if single else v.reshape(v.shape[0], -1, 32)
+        d_in = ctx.to_device(np.ascontiguousarray(batch))
+        d_out = ctx.empty_u8(batch.shape[0], 32)
+        ctx.call("wf_hash_merge_many_batch", cls.HASH_ID, ptr(d_in), batch.shape[0], batch.shape[1], ptr(d_out))
+        out = ctx.to_host(d_out)
+        return out[0] if single else out
+
+    @classmethod
     def merge_with_int(cls, seed, value, count=None, ctx=None):
         """Hasher::merge_with_int(seed, value) (crypto/src/hash/mod.rs:44-46); with `count`, the digests for
         value, value+1, ..., value+count-1 as a (count, 32) array (RandomCoin::next for a run of counters)."""
@@ -91,11 +106,7 @@ class Rp64_256(_Hasher):
     """crypto::hash::Rp64_256 (crypto/src/hash/rescue/rp64_256/mod.rs:123-257)."""
     HASH_ID = WF_HASH_RP64_256
 
-    @classmethod
-    def merge_many(cls, values, ctx=None):
-        """hash_elements over the digests' elements (rp64_256/mod.rs:194-196)."""
-        v = np.ascontiguousarray(values).view(np.uint64).reshape(-1)
-        return cls.hash_elements(v, ctx)
+    # merge_many: hash_elements over the digests' elements (rp64_256/mod.rs:194-196) — the base class's library call
 
     @staticmethod
     def digest_as_bytes(digest):
@@ -117,11 +128,6 @@ class Rp62_248(_Hasher):
     @classmethod
     def hash_elements(cls, elements, ctx=None, field=fields.f62):
         return super().hash_elements(elements, ctx, field)
-
-    @classmethod
-    def merge_many(cls, values, ctx=None):
-        v = np.ascontiguousarray(values).view(np.uint64).reshape(-1)
-        return cls.hash_elements(v, ctx)
 
     @staticmethod
     def digest_as_bytes(digest):
