@@ -136,3 +136,60 @@ def test_roots_of_unity_match_reference_constants(oracle):
     assert fields.f64.get_root_of_unity(6) == 8                        # omega_64 = 8: the shift-twiddle fact the NTT uses
     with pytest.raises(AssertionError):
         fields.f64.get_root_of_unity(33)
+
+
+@pytest.mark.parametrize("hid", [0, 1])
+def test_batch_proof_from_single_proofs_and_into_openings(oracle, hid):
+    """crypto/src/merkle/tests.rs:239-313 (from_proofs, batch_proof_from_proofs, verify_into_openings, into_openings):
+    aggregating the single openings gives exactly prove_batch's proof, and a batch proof decompresses into exactly the
+    single openings — over many random index sets, plus from_raw_parts (mod.rs:148-160)."""
+    from winterfell_amd.crypto import BatchMerkleProof, MerkleTree, MerkleTreeError
+    from conftest import splitmix64
+    h = _OracleHasher(oracle, hid)
+    rng = np.random.default_rng(11 + hid)
+    for log_n in (1, 2, 5, 7):
+        n = 1 << log_n
+        lv = (splitmix64(100 + log_n, n * 4) >> np.uint64(2)).view(np.uint8).reshape(n, 32)
+        tree = MerkleTree.from_raw_parts(h, oracle.merkle_build(hid, lv), lv)
+        assert tree.depth() == log_n and np.array_equal(tree.root(), oracle.merkle_build(hid, lv)[1])
+        for _ in range(12):
+            idx = sorted(set(int(v) for v in rng.integers(0, n, rng.integers(1, min(n, 20) + 1))))
+            leaves, bp = tree.prove_batch(idx)
+            singles = [tree.prove(i) for i in idx]
+            assert BatchMerkleProof.from_single_proofs(singles, idx) == bp, (log_n, idx)
+            # unsorted input order gives the same aggregate (the reference sorts through a BTreeMap)
+            perm = list(rng.permutation(len(idx)))
+            assert BatchMerkleProof.from_single_proofs([singles[k] for k in perm], [idx[k] for k in perm]) == bp
+            opened = bp.into_openings(h, leaves, idx)
+            for (leaf, path), (want_leaf, want_path) in zip(opened, singles):
+                assert np.array_equal(leaf, want_leaf) and len(path) == len(want_path)
+                assert all(np.array_equal(a, b) for a, b in zip(path, want_path))
+            for i, (leaf, path) in zip(idx, opened):
+                assert MerkleTree.verify(h, tree.root(), i, leaf, path) is None
+    with pytest.raises(AssertionError):
+        BatchMerkleProof.from_single_proofs([], [])
+    with pytest.raises(AssertionError):
+        BatchMerkleProof.from_single_proofs(singles, idx[:-1] if len(idx) > 1 else [])
+    with pytest.raises(MerkleTreeError, match="TooFewLeafIndexes"):
+        bp.into_openings(h, [], [])
+    with pytest.raises(MerkleTreeError, match="InvalidProof"):
+        bp.into_openings(h, leaves, idx + [0] if 0 not in idx else idx[:-1] + [])
+    with pytest.raises(MerkleTreeError, match="TooFewLeaves"):
+        MerkleTree.from_raw_parts(h, lv[:1], lv[:1])
+    with pytest.raises(MerkleTreeError, match="NotPowerOfTwo"):
+        MerkleTree.from_raw_parts(h, lv[:3], lv[:3])
+
+
+def test_vector_commitment_names(oracle):
+    """VectorCommitment for MerkleTree (crypto/src/merkle/mod.rs:401-458): same results under the trait's names."""
+    from winterfell_amd.crypto import MerkleTree
+    from conftest import splitmix64
+    h = _OracleHasher(oracle, 0)
+    lv = splitmix64(9, 16 * 4).view(np.uint8).reshape(16, 32)
+    tree = MerkleTree.from_raw_parts(h, oracle.merkle_build(0, lv), lv)
+    assert np.array_equal(tree.commitment(), tree.root()) and tree.domain_len() == 16
+    item, proof = tree.open(5)
+    assert MerkleTree.get_proof_domain_len(proof) == 16 and MerkleTree.verify(h, tree.commitment(), 5, item, proof) is None
+    items, mp = tree.open_many([2, 3, 9])
+    assert MerkleTree.get_multiproof_domain_len(mp) == 16
+    assert MerkleTree.verify_many(h, tree.commitment(), [2, 3, 9], items, mp) is None

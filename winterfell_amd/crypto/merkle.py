@@ -23,9 +23,49 @@ class BatchMerkleProof:
         self.nodes = nodes
         self.depth = depth
 
-    def get_root(self, hasher, indexes, leaves, ctx=None):
-        """proofs.rs:110-250: recompute the root from the opened leaves and the proof's sibling nodes.  The walk is
-        level by level over the set of known nodes; each level's merges run as one GPU batch."""
+    @classmethod
+    def from_single_proofs(cls, proofs, indexes):
+        """proofs.rs:38-108: aggregate single openings `(leaf, [sibling leaf, sibling nodes...])` (MerkleTree.prove's
+        output) into a batch proof.  Panics (AssertionError) on no proofs / length mismatch / unequal proof lengths."""
+        assert len(proofs) > 0, "at least one proof must be provided"
+        assert len(proofs) == len(indexes), "number of proofs must equal number of indexes"
+        depth = len(proofs[0][1])
+        by_index = {}
+        for idx, pr in zip(indexes, proofs):
+            assert len(pr[1]) == depth, "not all proofs have the same length"
+            by_index[idx] = pr
+        order = sorted(by_index)
+        nodes, level = [], []                      # level: [(node index at this depth, proof)] for the surviving chains
+        i = 0
+        while i < len(order):
+            pr = by_index[order[i]]
+            if i + 1 < len(order) and order[i] & 1 == 0 and order[i + 1] == order[i] + 1:
+                nodes.append([])                   # the sibling is itself an opened leaf
+                i += 1
+            else:
+                nodes.append([np.asarray(pr[1][0])])
+            level.append((order[i] >> 1, pr))
+            i += 1
+        for d in range(1, depth):
+            nxt, i = [], 0
+            while i < len(level):
+                idx, pr = level[i]
+                if i + 1 < len(level) and idx & 1 == 0 and level[i + 1][0] == idx + 1:
+                    i += 1
+                else:
+                    nodes[i].append(np.asarray(pr[1][d]))
+                nxt.append((idx >> 1, pr))
+                i += 1
+            # chains that merged keep the slot of the first of the pair, exactly like the BTreeMap walk of the reference
+            dedup = {}
+            for idx, pr in nxt:
+                dedup[idx] = pr
+            level = sorted(dedup.items())
+        return cls(nodes, depth)
+
+    def _resolve(self, hasher, indexes, leaves, ctx=None):
+        """Walk the proof up to the root (proofs.rs:110-236), one GPU merge batch per level.  Returns (root, known) with
+        `known` = {heap index: digest} of every node the walk touched (opened leaves, proof nodes, computed parents)."""
         if len(indexes) == 0:
             raise MerkleTreeError("TooFewLeafIndexes")
         n = 1 << self.depth
@@ -40,41 +80,73 @@ class BatchMerkleProof:
         if len(pairs) != len(self.nodes) or len(leaves) < len(indexes):
             raise MerkleTreeError("InvalidProof")
         used = [0] * len(pairs)                       # next unread proof node per pair (proof_pointers)
+        known = {}
 
         def take(i):
             if used[i] >= len(self.nodes[i]):
                 raise MerkleTreeError("InvalidProof")
             used[i] += 1
-            return np.asarray(self.nodes[i][used[i] - 1])
+            return np.asarray(self.nodes[i][used[i] - 1]).reshape(-1).view(np.uint8)
 
         batch = []
         for i, p in enumerate(pairs):
-            l = np.asarray(leaves[pos[p]]) if p in pos else take(i)
-            r = np.asarray(leaves[pos[p + 1]]) if p + 1 in pos else take(i)
-            batch.append(np.stack([l.reshape(-1).view(np.uint8), r.reshape(-1).view(np.uint8)]))
+            l = np.asarray(leaves[pos[p]]).reshape(-1).view(np.uint8) if p in pos else take(i)
+            r = np.asarray(leaves[pos[p + 1]]).reshape(-1).view(np.uint8) if p + 1 in pos else take(i)
+            known[n + p], known[n + p + 1] = l, r
+            batch.append(np.stack([l, r]))
         vals = hasher.merge(np.stack(batch), ctx).reshape(len(pairs), 32)
         cur = [(p + n) >> 1 for p in pairs]
+        for k, node in enumerate(cur):
+            known[node] = vals[k]
         for _ in range(1, self.depth):
-            known = {node: vals[k] for k, node in enumerate(cur)}
             nxt, batch = [], []
             k = 0
             while k < len(cur):
                 node, sib = cur[k], cur[k] ^ 1
                 if k + 1 < len(cur) and cur[k + 1] == sib:
-                    other = known[sib]
                     k += 1
                 else:
                     # proof nodes are filed under the node's position in this level's list (as prove_batch wrote them)
-                    other = take(k).reshape(-1).view(np.uint8)
-                a, b = (known[node], other) if node & 1 == 0 else (other, known[node])
+                    known[sib] = take(k)
+                a, b = (known[node], known[sib]) if node & 1 == 0 else (known[sib], known[node])
                 batch.append(np.stack([a, b]))
                 nxt.append(node >> 1)
                 k += 1
             vals = hasher.merge(np.stack(batch), ctx).reshape(len(nxt), 32)
             cur = nxt
+            for k, node in enumerate(cur):
+                known[node] = vals[k]
         if len(cur) != 1 or cur[0] != 1:
             raise MerkleTreeError("InvalidProof")
-        return vals[0]
+        return vals[0], known
+
+    def get_root(self, hasher, indexes, leaves, ctx=None):
+        """proofs.rs:110-236: recompute the root from the opened leaves and the proof's sibling nodes."""
+        return self._resolve(hasher, indexes, leaves, ctx)[0]
+
+    def into_openings(self, hasher, leaves, indexes, ctx=None):
+        """proofs.rs:244-380: the individual openings `(leaf, [sibling leaf, sibling nodes...])` this batch proof aggregates,
+        in the order of `indexes`."""
+        if len(indexes) == 0:
+            raise MerkleTreeError("TooFewLeafIndexes")
+        if len(indexes) != len(leaves):
+            raise MerkleTreeError("InvalidProof")
+        _, known = self._resolve(hasher, indexes, leaves, ctx)
+        n = 1 << self.depth
+        out = []
+        for idx in indexes:
+            node, path = idx + n, []
+            for _ in range(self.depth):
+                if (node ^ 1) not in known:
+                    raise MerkleTreeError("InvalidProof")
+                path.append(known[node ^ 1])
+                node >>= 1
+            out.append((known[idx + n], path))
+        return out
+
+    def __eq__(self, other):
+        return (isinstance(other, BatchMerkleProof) and self.depth == other.depth and len(self.nodes) == len(other.nodes)
+                and all(len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)) for a, b in zip(self.nodes, other.nodes)))
 
 
 class MerkleTree:
@@ -106,6 +178,26 @@ class MerkleTree:
                 raise MerkleTreeError("NumberOfLeavesNotPowerOfTwo(%d)" % n) from None
             raise
         return cls(hasher, d_leaves, d_nodes, ctx)
+
+    @classmethod
+    def from_raw_parts(cls, hasher, nodes, leaves, ctx=None):
+        """MerkleTree::from_raw_parts (mod.rs:148-160): adopt already computed nodes (heap layout) and leaves — what the
+        Rust shim does with the arrays the library built.  Numpy arrays stay on the host, device tensors on the device."""
+        nd = np.ascontiguousarray(nodes).view(np.uint8).reshape(-1, 32) if isinstance(nodes, np.ndarray) else nodes
+        lv = np.ascontiguousarray(leaves).view(np.uint8).reshape(-1, 32) if isinstance(leaves, np.ndarray) else leaves
+        n_nodes = len(nd) if isinstance(nd, np.ndarray) else nd.numel() // 32
+        n_leaves = len(lv) if isinstance(lv, np.ndarray) else lv.numel() // 32
+        if n_leaves < 2:
+            raise MerkleTreeError("TooFewLeaves(2, %d)" % n_leaves)
+        if n_leaves & (n_leaves - 1):
+            raise MerkleTreeError("NumberOfLeavesNotPowerOfTwo(%d)" % n_leaves)
+        assert n_nodes == n_leaves, "number of nodes must equal number of leaves"      # mod.rs:155
+        t = cls(hasher, None if isinstance(lv, np.ndarray) else lv, None if isinstance(nd, np.ndarray) else nd, ctx)
+        if isinstance(lv, np.ndarray):
+            t._leaves = lv
+        if isinstance(nd, np.ndarray):
+            t._nodes = nd
+        return t
 
     # ---- accessors ----------------------------------------------------------------------------------------
     @property
@@ -204,6 +296,35 @@ class MerkleTree:
         got = {"L": self._fetch("L", want_l), "N": self._fetch("N", want_n)}
         leaves = [got["L"][k] for k in leaf_slots]
         return leaves, BatchMerkleProof([[got[w][k] for w, k in lst] for lst in nodes], self.depth())
+
+    # ---- VectorCommitment for MerkleTree (mod.rs:401-458): the names the prover calls the tree by ----------------------------
+    @classmethod
+    def with_options(cls, hasher, items, options=None, ctx=None):
+        return cls.new(hasher, items, ctx)
+
+    def commitment(self):
+        return self.root()
+
+    def domain_len(self):
+        return 1 << self.depth()
+
+    @staticmethod
+    def get_proof_domain_len(proof):
+        return 1 << len(proof)
+
+    @staticmethod
+    def get_multiproof_domain_len(proof):
+        return 1 << proof.depth
+
+    def open(self, index):
+        return self.prove(index)
+
+    def open_many(self, indexes):
+        return self.prove_batch(indexes)
+
+    @staticmethod
+    def verify_many(hasher, commitment, indexes, items, proof, ctx=None):
+        return MerkleTree.verify_batch(hasher, commitment, indexes, items, proof, ctx)
 
     # ---- verification (mod.rs:283-307) ----------------------------------------------------------------------
     @staticmethod
