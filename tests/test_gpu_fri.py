@@ -212,3 +212,35 @@ def test_partitioned_fri_emulation_equals_verifier_layout(wf, oracle, world, hna
         for p, i in zip(positions, parallel.map_positions_to_indexes(positions, length, N, world)):
             assert np.array_equal(leaves[i], oracle.hash_elements(hid, rows[p]))
         length = rc
+
+
+def test_apply_drp_and_fold_positions_public_functions(wf, oracle):
+    """fri::folding::apply_drp / fold_positions as free functions (fri/src/folding/mod.rs:86-118, 159-176), and
+    FriProver::build_proof's layer queries (fri/src/prover/mod.rs:253-317)."""
+    ctx, crypto, fri, fields = wf
+    D, N, log_len = 2, 4, 10
+    ev = _lde_of_random_poly(oracle, log_len, 8, D, 99)
+    tr = oracle.transpose_slice(ev, N, D)
+    alpha = oracle.f64_from_int(rand_field(7, D))
+    got = fri.apply_drp(tr, fields.new(7), alpha, N, ext_degree=D)
+    assert np.array_equal(got, oracle.apply_drp(tr, N, oracle.f64_new(7), alpha, D))
+    assert fri.fold_positions([1, 9, 300, 44, 257 + 256], 1 << log_len, N) == [1, 9, 44]        # 300 % 256 = 44 first, 513 % 256 = 1 dropped
+    assert fri.fold_positions([5, 5 + 256, 5 + 512], 1 << log_len, N) == [5]
+    opts = fri.FriOptions(8, N, 7)
+    prover_ = fri.FriProver(opts, crypto.Blake3_256, ext_degree=D)
+    chan = oracle.ProverChannel(0, D)
+    prover_.build_layers(chan, ctx.to_device(ev))
+    layers = list(prover_.layers)
+    positions = [3, 700, 1023, 259]
+    proof = prover_.build_proof(positions)
+    assert prover_.num_layers() == 0 and proof.num_layers() == len(layers) and proof.num_partitions() == 1     # build_proof resets the prover
+    pos, length = positions, 1 << log_len
+    for li, layer in enumerate(layers):
+        pos = fri.fold_positions(pos, length, N)
+        rows = ctx.to_host(layer.evaluations)
+        assert np.array_equal(proof.layers[li].values, rows[pos])
+        leaves = crypto.Blake3_256.hash_elements(np.ascontiguousarray(proof.layers[li].values))
+        assert crypto.MerkleTree.verify_batch(crypto.Blake3_256, chan.commitments[li], pos, leaves, proof.layers[li].proof) is None
+        length //= N
+    with pytest.raises(AssertionError):
+        prover_.build_proof(positions)

@@ -134,10 +134,15 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
     length = N
     for li, layer in enumerate(fprover.layers):
         rc = length // folding
-        rows_idx = sorted(set(p % rc for p in pos))
-        leaves, mproof = layer.commitment.prove_batch(rows_idx)
-        assert crypto.MerkleTree.verify_batch(hasher, fchan.commitments[li], rows_idx, leaves, mproof) is None
+        # what FriProver::build_proof put into the proof for this layer: the queried rows, in fold_positions order, and
+        # the batch opening; the verifier hashes the rows into the leaves itself (fri/src/proof.rs:284-330)
+        rows_idx = fri.fold_positions(pos, length, folding)
+        assert sorted(rows_idx) == sorted(set(p % rc for p in pos))
+        player = proof.fri_proof.layers[li]
+        q_leaves = hasher.hash_elements(np.ascontiguousarray(player.values), field=fld)
+        assert crypto.MerkleTree.verify_batch(hasher, fchan.commitments[li], rows_idx, q_leaves, player.proof) is None
         rows = ctx.to_host(layer.evaluations)
+        assert all(np.array_equal(player.values[k], rows[r]) for k, r in enumerate(rows_idx))
         nxt_rows = ctx.to_host(fprover.layers[li + 1].evaluations) if li + 1 < len(fprover.layers) else None
         for r in rows_idx:
             if fname == "f64":
@@ -173,3 +178,5 @@ def test_prove_then_check(oracle, example, fname, hname, n, D):
                     assert acc == fld.unpack(full[r])
         pos, length = rows_idx, rc
     assert len(fchan.commitments) == fprover.num_layers() + 1
+    assert proof.fri_proof.num_layers() == fprover.num_layers() and proof.fri_proof.num_partitions() == 1
+    assert np.array_equal(proof.fri_proof.remainder, fprover.remainder_poly)

@@ -103,3 +103,85 @@ class FriProver:
         commitment = self.hasher.hash_elements(rem.reshape(-1), self.ctx, field=f)
         channel.commit_fri_layer(commitment)
         self.remainder_poly = rem
+
+
+    # ---- query phase (fri/src/prover/mod.rs:253-290, 296-317) ------------------------------------------------------------------
+    def build_proof(self, positions):
+        """FriProver::build_proof: for every layer the queried rows (N evaluations each, gathered from the device-resident
+        transposed layer) and the batch opening against the layer commitment; then the remainder.  Resets the prover."""
+        assert self.remainder_poly is not None, "FRI layers have not been built yet"
+        f, D, N = self.options.field, self.D, self.options.folding_factor
+        layers = []
+        if self.layers:
+            positions = list(positions)
+            domain_size = self.layers[0].evaluations.shape[0] * N
+            for layer in self.layers:
+                positions = fold_positions(positions, domain_size, N)
+                _, proof = layer.commitment.open_many(positions)
+                pos = np.ascontiguousarray(positions, dtype=np.uint64)
+                rows = np.empty((len(pos), N * D * f.W), dtype=np.uint64)
+                self.ctx.call("wf_rows_fetch", ptr(layer.evaluations), N * D, N * D, 8 * f.W, pos.ctypes.data_as(ctypes.c_void_p), len(pos),
+                              rows.ctypes.data_as(ctypes.c_void_p))
+                layers.append(FriProofLayer(rows, proof))
+                domain_size //= N
+        remainder = self.remainder_poly
+        self.reset()
+        return FriProof(layers, remainder, 1)
+
+
+def fold_positions(positions, source_domain_size, folding_factor):
+    """fri::folding::fold_positions (fri/src/folding/mod.rs:159-176): position mod the folded domain size, duplicates dropped
+    (first occurrence kept)."""
+    target = source_domain_size // folding_factor
+    out, seen = [], set()
+    for p in positions:
+        q = p % target
+        if q not in seen:
+            seen.add(q)
+            out.append(q)
+    return out
+
+
+class FriProofLayer:
+    """fri/src/proof.rs:240-270: the queried values of one layer (one row of N evaluations per folded position, in the order
+    of the positions) and the batch opening proof.  Kept as arrays; byte serialisation is out of scope."""
+
+    def __init__(self, query_values, proof):
+        assert len(query_values) > 0, "query values cannot be empty"
+        self.values, self.proof = query_values, proof
+
+
+class FriProof:
+    """fri/src/proof.rs:27-74."""
+
+    def __init__(self, layers, remainder, num_partitions=1):
+        assert len(remainder) > 0, "number of remainder elements must be greater than zero"
+        assert len(remainder) & (len(remainder) - 1) == 0, "size of the remainder must be a power of two, but was %d" % len(remainder)
+        assert num_partitions > 0 and num_partitions & (num_partitions - 1) == 0, "number of partitions must be a power of two, but was %d" % num_partitions
+        self.layers, self.remainder, self._log_partitions = layers, remainder, num_partitions.bit_length() - 1
+
+    def num_layers(self):
+        return len(self.layers)
+
+    def num_remainder_elements(self):
+        return len(self.remainder)
+
+    def num_partitions(self):
+        return 1 << self._log_partitions
+
+
+def apply_drp(values, domain_offset, alpha, folding_factor, ext_degree=1, ctx=None, field=fields.f64):
+    """fri::folding::apply_drp (fri/src/folding/mod.rs:86-118): `values` = the transposed layer (rows of N evaluations, flat),
+    returns the len/N folded evaluations.  alpha: ext_degree*W words; domain_offset: python int in internal form."""
+    ctx = ctx or default_context()
+    host = isinstance(values, np.ndarray)
+    d = ctx.to_device(values) if host else values
+    ew = ext_degree * field.W
+    length = d.numel() // ew
+    assert length & (length - 1) == 0 and folding_factor in (2, 4, 8, 16)
+    out = ctx.empty_u64((length // folding_factor) * ew)
+    off = field.element_words(int(domain_offset))
+    a = np.ascontiguousarray(alpha, dtype=np.uint64)
+    ctx.call("wf_fri_apply_drp", field.ID, ext_degree, ptr(d), length.bit_length() - 1, folding_factor, off.ctypes.data_as(ctypes.c_void_p),
+             a.ctypes.data_as(ctypes.c_void_p), ptr(out))
+    return ctx.to_host(out) if host else out

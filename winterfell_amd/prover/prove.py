@@ -74,13 +74,15 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
     lap("determine_query_positions", t0)
     # 7. openings (lib.rs:462-487)
     t0 = time.perf_counter()
+    fri_layers, fri_remainder = fri_prover.layers, fri_prover.remainder_poly      # kept for callers that inspect the layers
+    fri_proof = fri_prover.build_proof(query_positions)
     trace_queries = trace_lde.query(query_positions)
     constraint_queries = constraint_commitment.query(query_positions)
     lap("build_proof_object", t0)
     return Proof(options=options, commitments=channel.commitments, trace_commitment=trace_lde.get_main_trace_commitment(),
                  constraint_commitment=constraint_commitment.commitment(), ood_point=z, ood_trace_frame=ood_trace_states,
                  ood_constraint_frame=ood_evaluations, constraint_coefficients=evaluator.cc, assertions=evaluator.assertions,
-                 deep_coefficients=(cc_trace, cc_constraints), fri_layers=fri_prover.layers, fri_remainder=fri_prover.remainder_poly,
+                 deep_coefficients=(cc_trace, cc_constraints), fri_layers=fri_layers, fri_remainder=fri_remainder, fri_proof=fri_proof,
                  fri_alphas=channel.fri_alphas, fri_options=fri_options, pow_nonce=channel.pow_nonce, pow_seed=channel.pow_seed, query_positions=query_positions,
                  trace_queries=trace_queries, constraint_queries=constraint_queries, num_composition_columns=composition_poly.num_columns(),
                  timings_ms=tm)
