@@ -16,8 +16,10 @@
 // Field elements cross this layer exactly as they cross the C ABI: the reference's in-memory words (f64 / f62 Montgomery
 // u64, f128 canonical u128 as two u64), extension elements as consecutive base elements.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -220,6 +222,64 @@ class MerkleTree {
         return out;
     }
 
+    // MerkleTree::prove_batch (mod.rs:217-272): the opened leaves (in the order of `indexes`) and, per pair of sibling leaf
+    // positions, the proof nodes a verifier cannot recompute.  The walk only computes WHICH digests are needed; they come
+    // back in two device gathers.  Throws std::out_of_range / std::invalid_argument for LeafIndexOutOfBounds,
+    // TooFewLeafIndexes, DuplicateLeafIndex.
+    struct BatchProof {
+        std::vector<std::vector<std::vector<uint8_t>>> nodes;   // nodes[pair][k] = 32 bytes
+        uint32_t depth = 0;
+    };
+    std::pair<std::vector<std::vector<uint8_t>>, BatchProof> prove_batch(const std::vector<uint64_t> &indexes) const {
+        if (indexes.empty()) throw std::invalid_argument("TooFewLeafIndexes");
+        std::map<uint64_t, size_t> index_map;
+        for (size_t k = 0; k < indexes.size(); k++) {
+            if (indexes[k] >= n_) throw std::out_of_range("LeafIndexOutOfBounds");
+            if (!index_map.emplace(indexes[k], k).second) throw std::invalid_argument("DuplicateLeafIndex");
+        }
+        std::vector<uint64_t> pairs;
+        for (const auto &kv : index_map)
+            if (pairs.empty() || pairs.back() != (kv.first & ~1ull)) pairs.push_back(kv.first & ~1ull);
+        struct Ref { bool leaf; size_t slot; };
+        std::vector<uint64_t> want_l, want_n, cur;
+        std::vector<size_t> leaf_slot(indexes.size());
+        std::vector<std::vector<Ref>> refs(pairs.size());
+        for (size_t i = 0; i < pairs.size(); i++) {
+            for (uint64_t j = pairs[i]; j < pairs[i] + 2; j++) {
+                want_l.push_back(j);
+                auto it = index_map.find(j);
+                if (it != index_map.end()) leaf_slot[it->second] = want_l.size() - 1;
+                else refs[i].push_back(Ref{true, want_l.size() - 1});
+            }
+            cur.push_back((pairs[i] + n_) >> 1);
+        }
+        for (uint32_t d = 1; d < depth(); d++) {
+            std::vector<uint64_t> nxt;
+            for (size_t i = 0; i < cur.size(); i++) {
+                const uint64_t node = cur[i], sib = node ^ 1;
+                if (i + 1 < cur.size() && cur[i + 1] == sib) {
+                    i++;
+                } else {
+                    want_n.push_back(sib);
+                    refs[i].push_back(Ref{false, want_n.size() - 1});   // filed under the node's position in this level's list
+                }
+                nxt.push_back(sib >> 1);
+            }
+            cur.swap(nxt);
+        }
+        const std::vector<uint8_t> got_l = fetch(leaves_, want_l), got_n = fetch(nodes_, want_n);
+        auto digest = [](const std::vector<uint8_t> &v, size_t i) { return std::vector<uint8_t>(v.begin() + 32 * i, v.begin() + 32 * (i + 1)); };
+        std::vector<std::vector<uint8_t>> opened;
+        for (size_t k = 0; k < indexes.size(); k++) opened.push_back(digest(got_l, leaf_slot[k]));
+        BatchProof bp;
+        bp.depth = depth();
+        for (const auto &lst : refs) {
+            bp.nodes.emplace_back();
+            for (const Ref &r : lst) bp.nodes.back().push_back(digest(r.leaf ? got_l : got_n, r.slot));
+        }
+        return {opened, bp};
+    }
+
   private:
     Hash hash_;
     DeviceBuffer leaves_;
@@ -380,6 +440,49 @@ class FriProver {
         set_remainder(channel, evaluations, length);
     }
     const std::vector<FriLayer> &layers() const { return layers_; }
+    // fri::folding::fold_positions (fri/src/folding/mod.rs:159-176)
+    static std::vector<uint64_t> fold_positions(const std::vector<uint64_t> &positions, uint64_t source_domain_size, uint64_t folding_factor) {
+        const uint64_t target = source_domain_size / folding_factor;
+        std::vector<uint64_t> out;
+        for (uint64_t p : positions) {
+            const uint64_t q = p % target;
+            if (std::find(out.begin(), out.end(), q) == out.end()) out.push_back(q);
+        }
+        return out;
+    }
+    // one layer of FriProver::build_proof (mod.rs:253-317): the queried rows (N evaluations each, fold_positions order) and
+    // the batch opening against the layer commitment
+    struct ProofLayer {
+        std::vector<uint64_t> values;
+        MerkleTree::BatchProof proof;
+    };
+    struct Proof {
+        std::vector<ProofLayer> layers;
+        std::vector<uint64_t> remainder;
+        uint32_t num_partitions = 1;
+    };
+    // FriProver::build_proof: query phase; clears the layers (mod.rs:283-289)
+    Proof build_proof(std::vector<uint64_t> positions) {
+        if (remainder_.empty()) throw std::logic_error("FRI layers have not been built yet");
+        Proof out;
+        const uint64_t N = opts_.folding_factor;
+        const uint32_t row_words = (uint32_t)(N * D_ * words(field_));
+        uint64_t domain_size = layers_.empty() ? 0 : layers_[0].commitment.num_leaves() * N;
+        for (const FriLayer &layer : layers_) {
+            positions = fold_positions(positions, domain_size, N);
+            ProofLayer pl;
+            pl.proof = layer.commitment.prove_batch(positions).second;
+            pl.values.resize(positions.size() * row_words);
+            check(wf_rows_fetch(layer.evaluations.ctx().handle(), layer.evaluations.data(), N * D_, (uint32_t)(N * D_), 8 * words(field_), positions.data(),
+                                (uint32_t)positions.size(), pl.values.data()), "wf_rows_fetch");
+            out.layers.push_back(std::move(pl));
+            domain_size /= N;
+        }
+        out.remainder = remainder_;
+        layers_.clear();
+        remainder_.clear();
+        return out;
+    }
     // reversed coefficients of the remainder polynomial (mod.rs:230-239), ext_degree * W words each
     const std::vector<uint64_t> &remainder_poly() const { return remainder_; }
 

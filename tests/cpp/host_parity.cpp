@@ -125,6 +125,45 @@ int main() {
         auto proof = tc.tree.prove(5);
         EXPECT(proof.size() == tc.tree.depth() + 1 && std::memcmp(proof[1].data(), &o_leaves[4 * 32], 32) == 0 &&
                    std::memcmp(proof.back().data(), &o_nodes[3 * 32], 32) == 0, "MerkleTree::prove path");
+        {
+            // prove_batch vs a set-based restatement: at every level a sibling goes into the proof iff it is not itself on
+            // the path of an opened leaf; nodes are filed per pair of sibling leaf positions, in level order
+            const std::vector<uint64_t> idx = {700, 3, 2, 1500, 1501, 64};
+            auto pb = tc.tree.prove_batch(idx);
+            bool ok = pb.second.depth == tc.tree.depth() && pb.first.size() == idx.size();
+            for (size_t k = 0; k < idx.size() && ok; k++) ok = std::memcmp(pb.first[k].data(), &o_leaves[idx[k] * 32], 32) == 0;
+            std::vector<uint64_t> sorted = idx;
+            std::sort(sorted.begin(), sorted.end());
+            std::vector<uint64_t> pairs;
+            for (uint64_t v : sorted)
+                if (pairs.empty() || pairs.back() != (v & ~1ull)) pairs.push_back(v & ~1ull);
+            ok = ok && pb.second.nodes.size() == pairs.size();
+            size_t total = 0, want_total = 0;
+            for (const auto &lst : pb.second.nodes) total += lst.size();
+            // expected multiset of proof digests
+            std::vector<std::vector<uint8_t>> want;
+            std::vector<uint64_t> known(sorted);          // leaf level: heap index = N + leaf
+            for (auto &v : known) v += N;
+            for (uint32_t d = 0; d < tc.tree.depth(); d++) {
+                std::vector<uint64_t> nxt;
+                for (uint64_t node : known) {
+                    const uint64_t sib = node ^ 1;
+                    if (!std::binary_search(known.begin(), known.end(), sib)) {
+                        const uint8_t *src = d == 0 ? &o_leaves[(sib - N) * 32] : &o_nodes[sib * 32];
+                        want.emplace_back(src, src + 32);
+                        want_total++;
+                    }
+                    if (nxt.empty() || nxt.back() != node >> 1) nxt.push_back(node >> 1);
+                }
+                known.swap(nxt);
+            }
+            std::vector<std::vector<uint8_t>> got;
+            for (const auto &lst : pb.second.nodes)
+                for (const auto &dg : lst) got.push_back(dg);
+            std::sort(got.begin(), got.end());
+            std::sort(want.begin(), want.end());
+            EXPECT(ok && total == want_total && got == want, "MerkleTree::prove_batch (leaves in caller order, exactly the non-recomputable siblings)");
+        }
         std::vector<uint64_t> rows = tc.lde.rows({3, 700});
         EXPECT(std::memcmp(rows.data(), &o_lde[3 * rw], c * 8) == 0 && std::memcmp(&rows[c], &o_lde[700 * rw], c * 8) == 0, "TraceLde::query rows");
         // two-step path: evaluate_polys_over + commit_to_rows == the fused call
@@ -181,6 +220,23 @@ int main() {
         or_fri_remainder(0, cur.data(), length, D, offset, blowup, rem.data(), com);
         EXPECT(ok && prover.layers().size() == 3, "FriProver layers: nodes and transposed evaluations");
         EXPECT(prover.remainder_poly() == rem && std::memcmp(chan.commitments.back().data(), com, 32) == 0, "FRI remainder polynomial and its commitment");
+        // query phase: rows of every layer at the folded positions, in fold_positions order; build_proof resets the prover
+        std::vector<std::vector<uint64_t>> layer_rows;
+        for (const auto &l : prover.layers()) layer_rows.push_back(l.evaluations.to_host<uint64_t>());
+        const std::vector<uint64_t> positions = {5, 1029, 4000, 2053, 77};
+        EXPECT((wf::FriProver::fold_positions(positions, len, N) == std::vector<uint64_t>{5, 928, 77}), "fold_positions (duplicates dropped, first-seen order)");
+        wf::FriProver::Proof fp = prover.build_proof(positions);
+        bool qok = fp.layers.size() == layer_rows.size() && fp.remainder == rem && prover.layers().empty();
+        std::vector<uint64_t> pos = positions;
+        uint64_t dom = len;
+        for (size_t k = 0; k < fp.layers.size() && qok; k++) {
+            pos = wf::FriProver::fold_positions(pos, dom, N);
+            const size_t rw = N * D;
+            qok = fp.layers[k].values.size() == pos.size() * rw && fp.layers[k].proof.depth == wf::log2_exact(dom / N, "rows");
+            for (size_t q = 0; q < pos.size() && qok; q++) qok = std::memcmp(&fp.layers[k].values[q * rw], &layer_rows[k][pos[q] * rw], rw * 8) == 0;
+            dom /= N;
+        }
+        EXPECT(qok, "FriProver::build_proof: queried rows per layer, remainder, reset");
     }
 
     // ---- fib_small: constraint evaluation, OOD frame, DEEP composition, grinding ------------------------------------------------------
