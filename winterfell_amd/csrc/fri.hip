@@ -115,6 +115,14 @@ int layer_commit(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
     const dim3 grid((uint32_t)((rc + 255) / 256)), block(256);
     const T *ev = (const T *)d_evals;
     T *tr = (T *)d_transposed;
+    // transpose + leaf hashes in one pass where that is the faster arrangement (hash_kernels.hip)
+    int fused = 0;
+    WF_TRY(wf_fri_transpose_hash(ctx, hash, HF::Dev::ID, D, d_evals, log_rc, log_nf, d_transposed, d_leaves, &fused));
+    if (fused) {
+        WF_TRY(wf_merkle_build(ctx, hash, d_leaves, rc, d_nodes));
+        if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_nodes + 32, 32));
+        return WF_OK;
+    }
     wf_prof_begin(ctx, "fri_transpose");
     if (D == 1) hipLaunchKernelGGL((fri_transpose_kernel<T, 1>), grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);
     else if (D == 2) hipLaunchKernelGGL((fri_transpose_kernel<T, 2>), grid, block, 0, ctx->stream, ev, tr, log_rc, log_nf);

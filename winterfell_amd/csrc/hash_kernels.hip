@@ -513,6 +513,57 @@ int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint6
 #undef WF_HR
 }
 
+// FRI layer commit, first half, in one pass (fri/src/prover/mod.rs:321-336 = transpose_slice + hash each row):
+//   tr[i][j] = ev[i + j * rc]   and   leaf_i = H::hash_elements(tr[i]).
+// A workgroup takes R consecutive rows: the N strided runs of R elements are read coalesced into an LDS tile
+// [R][row_words + 1], every lane hashes its row straight out of the tile, and the tile is written to the transposed matrix
+// as ONE contiguous block.  (The separate transpose wrote 8 or 16 bytes per lane at a row-sized stride — 1 TB/s — and the
+// row hash then read the matrix back.)  EW = 64-bit words per element (ext_degree * words per base element).
+template <class H, int MODE>
+__global__ __launch_bounds__(256) void fri_rows_kernel(const uint64_t *ev, uint64_t rc, uint32_t N, uint32_t EW, uint32_t R, uint64_t *tr,
+                                                       void *leaves) {
+    extern __shared__ uint64_t fri_tile[];
+    const uint32_t row_words = N * EW, pitch = row_words + 1;
+    const uint64_t r0 = (uint64_t)blockIdx.x * R;
+    const uint32_t nr = rc - r0 < R ? (uint32_t)(rc - r0) : R;
+    const uint32_t run = nr * EW;                        // consecutive words of one strided run
+    for (uint32_t idx = threadIdx.x; idx < N * run; idx += 256) {
+        const uint32_t j = idx / run, k = idx - j * run;
+        fri_tile[(k / EW) * pitch + j * EW + (k % EW)] = ev[(r0 + (uint64_t)j * rc) * EW + k];
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nr; t += 256) {
+        uint32_t d[8];
+        H::template hash_elems<MODE, false>(fri_tile + t * pitch, row_words, d);
+        store_digest(leaves, r0 + t, d);
+    }
+    for (uint32_t idx = threadIdx.x; idx < nr * row_words; idx += 256) {
+        const uint32_t r = idx / row_words, w = idx - r * row_words;
+        tr[r0 * row_words + idx] = fri_tile[r * pitch + w];
+    }
+}
+
+template <class H>
+int launch_fri_rows(wf_ctx *ctx, int mode, const uint64_t *ev, uint64_t rc, uint32_t N, uint32_t EW, uint64_t *tr, void *leaves) {
+    const uint32_t pitch = N * EW + 1;
+    uint32_t R = 256;
+    while (R > 32 && (size_t)R * pitch * 8 > 40960) R >>= 1;
+    const uint64_t blocks = (rc + R - 1) / R;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    const size_t lds = (size_t)R * pitch * 8;
+    wf_prof_begin(ctx, "fri_transpose_hash");
+#define WF_FR(MODE) hipLaunchKernelGGL((fri_rows_kernel<H, MODE>), dim3((uint32_t)blocks), dim3(256), lds, ctx->stream, ev, rc, N, EW, R, tr, leaves)
+    switch (mode) {
+        case MODE_F64_CANON: WF_FR(MODE_F64_CANON); break;
+        case MODE_F62_CANON: WF_FR(MODE_F62_CANON); break;
+        default: WF_FR(MODE_RAW); break;
+    }
+#undef WF_FR
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
 template <class H>
 int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *nodes) {
     WF_HIP(hipMemsetAsync(nodes, 0, 32, ctx->stream));  // nodes[0] = Digest::default()
@@ -576,6 +627,25 @@ int with_hasher(int hash, FN &&fn) {
 }
 
 }  // namespace
+
+// used by wf_fri_layer_commit (fri.hip): *done = 0 when the caller should take the unfused path (small Rescue layers, where the
+// lane-cooperative row hash wins)
+int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
+                          void *d_transposed, void *d_leaves, int *done) {
+    *done = 0;
+    WF_TRY(check_hash(hash));
+    if (field != WF_FIELD_F64 && (hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256)) return WF_ERR_UNSUPPORTED;
+    if (field != WF_FIELD_F62 && hash == WF_HASH_RP62_248) return WF_ERR_UNSUPPORTED;
+    const uint64_t rc = 1ull << log_rc;
+    const bool rescue = hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256 || hash == WF_HASH_RP62_248;
+    if (rescue && rc <= rcoop::COOP_MAX) return WF_OK;
+    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : (field == WF_FIELD_F62 ? MODE_F62_CANON : MODE_RAW);
+    const uint32_t EW = ext_degree * (field == WF_FIELD_F128 ? 2 : 1);
+    *done = 1;
+    return with_hasher(hash, [&](auto h) {
+        return launch_fri_rows<decltype(h)>(ctx, mode, (const uint64_t *)d_evals, rc, 1u << log_nf, EW, (uint64_t *)d_transposed, d_leaves);
+    });
+}
 
 extern "C" int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint64_t num_leaves, void *d_nodes) {
     if (!ctx || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;

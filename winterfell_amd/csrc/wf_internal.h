@@ -118,6 +118,8 @@ struct NttJob {
     uint32_t rm_log_b = 0, rm_log_i = 0, rm_base_cols = 0;
     uint64_t rm_row_width = 0;
 };
+int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
+                          void *d_transposed, void *d_leaves, int *done);   // hash_kernels.hip
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field
 int wf_ntt_run_f64(wf_ctx *ctx, const NttJob &job);
 int wf_ntt_run_f128(wf_ctx *ctx, const NttJob &job);
