@@ -160,4 +160,67 @@ __device__ __forceinline__ void hash_words(const W &w, uint32_t nwords, uint32_t
     for (int i = 0; i < 8; i++) out[i] = cv[i];
 }
 
+// ---- block-source variants ---------------------------------------------------------------------------------------
+// FB: callable  fetch(block_index, nwords_valid, m)  that fills the 16 message words of 64-byte block `block_index` of the
+// whole message (words past nwords_valid zero).  Same chunk / tree structure as above; lets a wavefront bring a block of
+// 64 rows in cooperatively (hash_kernels.hip, wide rows) instead of every lane walking its own row.
+template <class FB>
+__device__ __forceinline__ void chunk_blocks(const FB &fetch, uint32_t blk0, uint32_t nwords_chunk, uint32_t chunk_counter, bool root,
+                                             uint32_t (&out)[8]) {
+    uint32_t cv[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) cv[i] = iv(i);
+    const uint32_t nblocks = nwords_chunk == 0 ? 1 : (nwords_chunk + 15) / 16;
+    for (uint32_t blk = 0; blk < nblocks; blk++) {
+        uint32_t m[16];
+        const uint32_t left = nwords_chunk - blk * 16;
+        fetch(blk0 + blk, left >= 16 ? 16u : left, m);
+        const uint32_t block_len = left >= 16 ? 64u : left * 4u;
+        uint32_t flags = (blk == 0 ? CHUNK_START : 0u) | (blk + 1 == nblocks ? CHUNK_END : 0u);
+        if (root && blk + 1 == nblocks) flags |= ROOT;
+        uint32_t o[8];
+        compress(cv, m, (flags & ROOT) ? 0u : chunk_counter, block_len, flags, o);
+#pragma unroll
+        for (int i = 0; i < 8; i++) cv[i] = o[i];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
+template <class FB>
+__device__ __forceinline__ void hash_blocks(const FB &fetch, uint32_t nwords, uint32_t (&out)[8]) {
+    if (nwords <= 256) {
+        chunk_blocks(fetch, 0, nwords, 0, true, out);
+        return;
+    }
+    const uint32_t nchunks = (nwords + 255) / 256;
+    uint32_t stack[12][8];
+    int sp = 0;
+    uint32_t cv[8];
+    for (uint32_t c = 0; c + 1 < nchunks; c++) {
+        chunk_blocks(fetch, c * 16, 256, c, false, cv);
+        uint32_t total = c + 1;
+        while ((total & 1u) == 0) {
+            sp--;
+            uint32_t l[8], o[8];
+            for (int i = 0; i < 8; i++) l[i] = stack[sp][i];
+            parent(l, cv, false, o);
+            for (int i = 0; i < 8; i++) cv[i] = o[i];
+            total >>= 1;
+        }
+        for (int i = 0; i < 8; i++) stack[sp][i] = cv[i];
+        sp++;
+    }
+    const uint32_t last = nchunks - 1;
+    chunk_blocks(fetch, last * 16, nwords - last * 256, last, false, cv);
+    while (sp > 0) {
+        sp--;
+        uint32_t l[8], o[8];
+        for (int i = 0; i < 8; i++) l[i] = stack[sp][i];
+        parent(l, cv, sp == 0, o);
+        for (int i = 0; i < 8; i++) cv[i] = o[i];
+    }
+    for (int i = 0; i < 8; i++) out[i] = cv[i];
+}
+
 }  // namespace b3

@@ -201,7 +201,14 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
     j.pre_lo_stride = los;
     j.pre_hi_stride = his;
     // Output vector v = bc*b + u is coset u of base column bc; element m of it is LDE row u + b*m.
-    const uint32_t log_i = base_cols >= 8 ? 3 : (base_cols >= 4 ? 2 : (base_cols >= 2 ? 1 : 0));
+#ifndef WF_RM_MAX_LOG_I
+#define WF_RM_MAX_LOG_I 5
+#endif
+    // columns per contiguous row segment of the fused row-major store: as many as the matrix has, up to 32 (a tile of the
+    // last pass spans 16 or 32 (vector, column) pairs, so a row then receives 128-512 contiguous bytes per workgroup)
+    uint32_t log_i = 0;
+    const uint32_t max_log_i = sizeof(T) > 8 && WF_RM_MAX_LOG_I > 4 ? 4 : WF_RM_MAX_LOG_I;   // 256-byte segments
+    while (log_i < max_log_i && (2u << log_i) <= base_cols) log_i++;
     if (((size_t)sizeof(T) << log_i) >= 64) {
         // wide rows: the last pass stores straight into the row-major matrix, >= 64 contiguous bytes per row and column
         // group, and zeroes the padding columns (NttJob::rowmajor).  Measured on 64 x 2^22 f128 columns: the separate

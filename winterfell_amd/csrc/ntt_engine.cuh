@@ -378,7 +378,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     p.rm_log_i = job.rm_log_i;
     p.rm_base_cols = job.rm_base_cols;
     p.rm_row_width = job.rm_row_width;
-    if (job.rowmajor && (job.nvec != (job.rm_base_cols << job.rm_log_b) || job.rm_log_i > 3)) return WF_ERR_INVALID_ARG;
+    if (job.rowmajor && (job.nvec != (job.rm_base_cols << job.rm_log_b) || job.rm_log_i > 5)) return WF_ERR_INVALID_ARG;
 
     const uint64_t n = 1ull << L;
     T *tmp = nullptr;
