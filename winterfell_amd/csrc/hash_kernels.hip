@@ -31,7 +31,20 @@ struct Digest {
 // ---- per-hasher primitives on 32-byte digests ----------------------------------------------------------------
 struct HBlake3 {
     static constexpr bool WIDE = true;               // rows of >= 64 bytes: wave-cooperative block loads (hash_rows_wide_kernel)
-    static __device__ __forceinline__ void finish(uint32_t (&)[8]) {}
+    static constexpr int WIDE_BW = 8;                // 64-bit words per message block
+    template <class FB>
+    static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
+        auto fetch = [&](uint32_t blk, uint32_t, uint32_t (&m)[16]) {
+            uint64_t v[8];
+            fetch64(blk, v);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                m[2 * i] = (uint32_t)v[i];
+                m[2 * i + 1] = (uint32_t)(v[i] >> 32);
+            }
+        };
+        b3::hash_blocks(fetch, nelem * 2, out);
+    }
     static constexpr bool COOP = false;
     // levels reduced per Merkle launch: BLAKE3 merges are cheap, so a workgroup walks 10 levels through LDS
     static constexpr uint32_t STAGE_LEVELS = 10;
@@ -73,7 +86,12 @@ struct HBlake3 {
 // for merge_many, seed[..24] || value for merge_with_int).
 struct HBlake3_192 {
     static constexpr bool WIDE = true;
-    static __device__ __forceinline__ void finish(uint32_t (&out)[8]) { out[6] = out[7] = 0; }
+    static constexpr int WIDE_BW = 8;
+    template <class FB>
+    static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
+        HBlake3::hash_wide(fetch64, nelem, out);
+        out[6] = out[7] = 0;
+    }
     static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 10;
     static const char *row_name() { return "hash_rows_blake3_192"; }
@@ -233,7 +251,18 @@ struct HRp62 {
 
 // Sha3_256<B> (crypto/src/hash/sha/mod.rs:21-66): same byte-level structure as Blake3_256 with SHA3-256 as the byte hash
 struct HSha3 {
-    static constexpr bool WIDE = false;
+    static constexpr bool WIDE = true;
+    static constexpr int WIDE_BW = 17;               // the 136-byte rate
+    template <class FB>
+    static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
+        uint64_t d[4];
+        k3::sha3_256_blocks(fetch64, nelem, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
     static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 8;
     static const char *row_name() { return "hash_rows_sha3"; }
@@ -470,7 +499,9 @@ __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint
 template <class H, int MODE>
 __global__ __launch_bounds__(256) void hash_rows_wide_kernel(const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
                                                              uint32_t part_elems, uint32_t parts, void *out) {
-    __shared__ uint64_t stage_all[4][64 * 9];
+    constexpr int BW = H::WIDE_BW;                                    // 64-bit words per message block (BLAKE3 8, SHA3 17)
+    constexpr int PITCH = BW | 1;                                     // odd: lanes reading their own rows hit distinct banks
+    __shared__ uint64_t stage_all[4][64 * PITCH];
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     volatile uint64_t *st = stage_all[wave];
     const uint64_t r_base = ((uint64_t)blockIdx.x * 4 + wave) * 64;
@@ -479,12 +510,12 @@ __global__ __launch_bounds__(256) void hash_rows_wide_kernel(const uint64_t *row
     const uint32_t e0 = k * part_elems;
     const uint32_t e1 = (e0 + part_elems < elems_per_row) ? e0 + part_elems : elems_per_row;
     const uint32_t nelem = e1 - e0;
-    const uint32_t wq = lane & 7, rq = lane >> 3;
-    auto fetch = [&](uint32_t blk, uint32_t, uint32_t (&m)[16]) {
-        const uint32_t wi = blk * 8 + wq;                             // 64-bit word of the row part this lane loads
+    auto fetch64 = [&](uint32_t blk, uint64_t (&m)[BW]) {
 #pragma unroll
-        for (uint32_t q = 0; q < 8; q++) {
-            const uint32_t rl = q * 8 + rq;
+        for (uint32_t it = 0; it < BW; it++) {                        // 64 * BW words, 64 per step: runs of BW words per row
+            const uint32_t idx = it * 64 + lane;
+            const uint32_t rl = idx / BW, wq = idx - rl * BW;
+            const uint32_t wi = blk * BW + wq;                        // word of the row part
             uint64_t row = r_base + rl;
             if (row >= num_rows) row = num_rows - 1;
             uint64_t v = 0;
@@ -493,18 +524,13 @@ __global__ __launch_bounds__(256) void hash_rows_wide_kernel(const uint64_t *row
                 if (MODE == MODE_F64_CANON) v = gl::to_int(v);
                 else if (MODE == MODE_F62_CANON) v = f62::mul(f62::norm(v), 1);
             }
-            st[rl * 9 + wq] = v;
+            st[rl * PITCH + wq] = v;
         }
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint64_t v = st[lane * 9 + i];
-            m[2 * i] = (uint32_t)v;
-            m[2 * i + 1] = (uint32_t)(v >> 32);
-        }
+        for (int i = 0; i < BW; i++) m[i] = st[lane * PITCH + i];
     };
     uint32_t d[8];
-    b3::hash_blocks(fetch, nelem * 2, d);
-    H::finish(d);
+    H::hash_wide(fetch64, nelem, d);
     if (r_base + lane < num_rows) store_digest(out, (r_base + lane) * parts + k, d);
 }
 
@@ -534,7 +560,7 @@ int launch_hash_rows_t(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uin
     const uint64_t blocks = (num_rows + 255) / 256;
     if (blocks > 0x7fffffffull || parts > 65535) return WF_ERR_DOMAIN_TOO_LARGE;
     if constexpr (H::WIDE) {
-        if (MODE != MODE_DIGESTS && part_elems >= 8 && elems_per_row >= 8) {
+        if (MODE != MODE_DIGESTS && part_elems >= (uint32_t)H::WIDE_BW && elems_per_row >= (uint32_t)H::WIDE_BW) {
             wf_prof_begin(ctx, H::row_name());
             hipLaunchKernelGGL((hash_rows_wide_kernel<H, MODE>), dim3((uint32_t)blocks, parts), dim3(256), 0, ctx->stream, rows, num_rows, row_width,
                                elems_per_row, part_elems, parts, out);

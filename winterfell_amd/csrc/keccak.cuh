@@ -65,4 +65,29 @@ __device__ __forceinline__ void sha3_256_words(const W &w, uint32_t n, uint64_t 
     for (int i = 0; i < 4; i++) digest[i] = st[i];
 }
 
+// the same sponge with a block source: fetch(blk, m) fills the 17 words of rate block `blk` (words past the message zero);
+// n = message length in words.  Lets a wavefront load the blocks of 64 rows cooperatively (hash_kernels.hip, wide rows).
+template <class FB>
+__device__ __forceinline__ void sha3_256_blocks(const FB &fetch, uint32_t n, uint64_t (&digest)[4]) {
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const uint32_t full = n / 17, left = n - full * 17;
+    for (uint32_t blk = 0; blk <= full; blk++) {
+        uint64_t m[17];
+        fetch(blk, m);
+#pragma unroll
+        for (int k = 0; k < 17; k++) st[k] ^= m[k];
+        if (blk == full) {
+#pragma unroll
+            for (int k = 0; k < 17; k++)
+                if ((uint32_t)k == left) st[k] ^= 0x06ull;
+            st[16] ^= 0x8000000000000000ull;
+        }
+        f1600(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) digest[i] = st[i];
+}
+
 }  // namespace k3
