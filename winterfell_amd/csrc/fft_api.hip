@@ -167,9 +167,11 @@ int interpolate_with_offset(wf_ctx *ctx, uint32_t D, void *d_evals, uint32_t log
     return wf_ntt_run(ctx, j);
 }
 
+// hash >= 0: the caller also wants the row hashes (wf_build_trace_commitment, one partition); when the narrow-row path
+// is taken and a row is one 8-column group, transpose and leaf hashing run as ONE kernel and *fused is set
 template <class HF>
 int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t num_cols, uint64_t col_stride, uint32_t log_n,
-                        uint32_t log_blowup, const void *h_offset, void *d_lde) {
+                        uint32_t log_blowup, const void *h_offset, void *d_lde, int hash, void *d_leaves, int *fused) {
     typedef typename HF::T T;
     WF_TRY(check_ext<HF>(D));
     WF_TRY(check_domain<HF>(log_n + log_blowup));
@@ -235,6 +237,14 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
     const uint64_t blocks = m_tiles * (row_width / 8);
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
     const size_t lds_bytes = ((size_t)1 << log_tm) * (b * 8 + 1) * sizeof(T);
+    if (hash >= 0 && row_width == 8 && ((uint64_t)b << log_tm) <= 256) {
+        int done = 0;
+        WF_TRY(wf_lde_transpose_hash(ctx, hash, HF::Dev::ID, D, tmpv, d_lde, base_cols, log_n, log_blowup, log_tm, d_leaves, &done));
+        if (done) {
+            *fused = 1;
+            return WF_OK;
+        }
+    }
     wf_prof_begin(ctx, "lde_transpose");
     hipLaunchKernelGGL(lde_transpose_kernel<T>, dim3((uint32_t)blocks), dim3(256), lds_bytes, ctx->stream, (const T *)tmpv,
                        (T *)d_lde, base_cols, row_width, log_n, log_blowup, log_tm);
@@ -296,11 +306,20 @@ extern "C" int wf_interpolate_columns(wf_ctx *ctx, int field, uint32_t ext_degre
     WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_cols, log_n, num_cols, true, col_stride);
 }
 
+int wf_evaluate_polys_over_fused(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols, uint64_t col_stride,
+                                 uint32_t log_n, uint32_t log_blowup, const void *h_offset, void *d_lde, int hash, void *d_leaves, int *fused) {
+    *fused = 0;
+    if (!ctx || !d_polys || !d_lde || num_cols == 0 || log_n == 0) return WF_ERR_INVALID_ARG;
+    WF_DISPATCH_FIELD(field, evaluate_polys_over, ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde, hash,
+                      d_leaves, fused);
+}
+
 extern "C" int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
                                       uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
                                       void *d_lde) {
-    if (!ctx || !d_polys || !d_lde || num_cols == 0 || log_n == 0) return WF_ERR_INVALID_ARG;
-    WF_DISPATCH_FIELD(field, evaluate_polys_over, ctx, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde);
+    int fused;
+    return wf_evaluate_polys_over_fused(ctx, field, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde, -1, nullptr,
+                                        &fused);
 }
 
 extern "C" int wf_evaluate_columns_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,

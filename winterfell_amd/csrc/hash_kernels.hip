@@ -604,6 +604,65 @@ int launch_hash_rows(wf_ctx *ctx, const uint64_t *rows, uint64_t num_rows, uint6
 #undef WF_HR
 }
 
+// Narrow traces (one 8-column group per row): the LDE transpose of fft_api.hip (coset-major tmp[bc][u][m] -> row-major
+// lde[(u + b*m)][8]) with the leaf hash folded in.  A tile holds b * TM <= 256 COMPLETE rows in LDS, so after the coalesced
+// row-major store every lane hashes one row straight from the tile: the separate row-hash kernel, and its read of the
+// whole matrix, disappear.  W = 64-bit words per base element.
+template <class H, int MODE, class T>
+__global__ __launch_bounds__(256) void lde_transpose_hash_kernel(const T *tmp, T *lde, uint32_t base_cols, uint32_t log_n, uint32_t log_b,
+                                                                uint32_t log_tm, void *leaves) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lde_smem[];
+    T *tile = reinterpret_cast<T *>(lde_smem);
+    constexpr uint32_t W = sizeof(T) / 8;
+    const uint64_t n = 1ull << log_n;
+    const uint32_t b = 1u << log_b, TM = 1u << log_tm;
+    const uint32_t row = b * 8 + 1;
+    const uint64_t mt = blockIdx.x;
+    const uint32_t total = b * 8 * TM;
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+        const uint32_t ml = idx & (TM - 1), uc = idx >> log_tm;
+        const uint32_t u = uc & (b - 1), cl = uc >> log_b;
+        const uint64_t m = (mt << log_tm) + ml;
+        T v = 0;
+        if (cl < base_cols && m < n) v = tmp[(((uint64_t)cl << log_b) + u) * n + m];
+        tile[ml * row + u * 8 + cl] = v;
+    }
+    __syncthreads();
+    for (uint32_t idx = threadIdx.x; idx < total; idx += 256) {
+        const uint32_t cl = idx & 7, u = (idx >> 3) & (b - 1), ml = idx >> (3 + log_b);
+        const uint64_t m = (mt << log_tm) + ml;
+        if (m < n) lde[(u + ((uint64_t)m << log_b)) * 8 + cl] = tile[ml * row + u * 8 + cl];
+    }
+    for (uint32_t r = threadIdx.x; r < b * TM; r += 256) {
+        const uint32_t u = r & (b - 1), ml = r >> log_b;
+        const uint64_t m = (mt << log_tm) + ml;
+        if (m >= n) continue;
+        uint32_t d[8];
+        H::template hash_elems<MODE, false>(reinterpret_cast<const uint64_t *>(tile + ml * row + u * 8), base_cols * W, d);
+        store_digest(leaves, u + (m << log_b), d);
+    }
+}
+
+template <class H, class T>
+int launch_lde_transpose_hash(wf_ctx *ctx, int mode, const void *tmp, void *lde, uint32_t base_cols, uint32_t log_n, uint32_t log_b,
+                              uint32_t log_tm, void *leaves) {
+    const uint64_t n = 1ull << log_n;
+    const uint64_t blocks = (n + (1ull << log_tm) - 1) >> log_tm;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    const size_t lds = ((size_t)1 << log_tm) * ((8u << log_b) + 1) * sizeof(T);
+    wf_prof_begin(ctx, "lde_transpose_hash");
+#define WF_LT(MODE) hipLaunchKernelGGL((lde_transpose_hash_kernel<H, MODE, T>), dim3((uint32_t)blocks), dim3(256), lds, ctx->stream, (const T *)tmp, (T *)lde, base_cols, log_n, log_b, log_tm, leaves)
+    switch (mode) {
+        case MODE_F64_CANON: WF_LT(MODE_F64_CANON); break;
+        case MODE_F62_CANON: WF_LT(MODE_F62_CANON); break;
+        default: WF_LT(MODE_RAW); break;
+    }
+#undef WF_LT
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
 // FRI layer commit, first half, in one pass (fri/src/prover/mod.rs:321-336 = transpose_slice + hash each row):
 //   tr[i][j] = ev[i + j * rc]   and   leaf_i = H::hash_elements(tr[i]).
 // A workgroup takes R consecutive rows: the N strided runs of R elements are read coalesced into an LDS tile
@@ -718,6 +777,23 @@ int with_hasher(int hash, FN &&fn) {
 }
 
 }  // namespace
+
+// used by wf_build_trace_commitment through wf_evaluate_polys_over_fused (fft_api.hip).  Only the byte hashers take the fused
+// path: a Rescue row hash is three orders of magnitude more arithmetic than the transpose it would be fused with.
+int wf_lde_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_tmp, void *d_lde, uint32_t base_cols,
+                          uint32_t log_n, uint32_t log_b, uint32_t log_tm, void *d_leaves, int *done) {
+    *done = 0;
+    if (hash != WF_HASH_BLAKE3_256 && hash != WF_HASH_BLAKE3_192 && hash != WF_HASH_SHA3_256) return WF_OK;
+    if (!d_leaves) return WF_ERR_INVALID_ARG;
+    (void)ext_degree;
+    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : (field == WF_FIELD_F62 ? MODE_F62_CANON : MODE_RAW);
+    *done = 1;
+    return with_hasher(hash, [&](auto h) {
+        typedef decltype(h) H;
+        if (field == WF_FIELD_F128) return launch_lde_transpose_hash<H, f128::u128>(ctx, mode, d_tmp, d_lde, base_cols, log_n, log_b, log_tm, d_leaves);
+        return launch_lde_transpose_hash<H, uint64_t>(ctx, mode, d_tmp, d_lde, base_cols, log_n, log_b, log_tm, d_leaves);
+    });
+}
 
 // used by wf_fri_layer_commit (fri.hip): *done = 0 when the caller should take the unfused path (small Rescue layers, where the
 // lane-cooperative row hash wins)
@@ -958,11 +1034,22 @@ extern "C" int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint3
     WF_TRY(check_hash(hash));
     // extend_execution_trace
     if (!skip_interpolate) WF_TRY(wf_interpolate_columns(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n));
-    WF_TRY(wf_evaluate_polys_over(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde));
-    // compute_execution_trace_commitment
+    if (ext_degree == 0 || num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
+    // (for narrow traces committed with a byte hasher and no partitions the LDE transpose also produces the row hashes)
     const uint64_t N = 1ull << (log_n + log_blowup);
     const uint64_t rw = wf_row_width(num_cols, ext_degree);
-    WF_TRY(wf_hash_rows(ctx, hash, field, ext_degree, d_lde, N, rw, num_cols * ext_degree, num_partitions, hash_rate, d_leaves));
+    bool one_partition = num_partitions == 1;
+    if (!one_partition) {   // PartitionOptions::partition_size (air/src/options.rs:428-437): one partition if it covers all columns
+        const uint32_t min_ps = hash_rate / ext_degree;
+        uint32_t ps = (num_cols + num_partitions - 1) / num_partitions;
+        if (ps < min_ps) ps = min_ps;
+        one_partition = ps >= num_cols;
+    }
+    int fused = 0;
+    WF_TRY(wf_evaluate_polys_over_fused(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde,
+                                        one_partition ? hash : -1, d_leaves, &fused));
+    // compute_execution_trace_commitment
+    if (!fused) WF_TRY(wf_hash_rows(ctx, hash, field, ext_degree, d_lde, N, rw, num_cols * ext_degree, num_partitions, hash_rate, d_leaves));
     WF_TRY(wf_merkle_build(ctx, hash, d_leaves, N, d_nodes));
     if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_nodes + 32, 32));
     return WF_OK;

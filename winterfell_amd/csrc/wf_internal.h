@@ -118,6 +118,11 @@ struct NttJob {
     uint32_t rm_log_b = 0, rm_log_i = 0, rm_base_cols = 0;
     uint64_t rm_row_width = 0;
 };
+int wf_evaluate_polys_over_fused(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols, uint64_t col_stride,
+                                 uint32_t log_n, uint32_t log_blowup, const void *h_offset, void *d_lde, int hash, void *d_leaves,
+                                 int *fused);   // fft_api.hip
+int wf_lde_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_tmp, void *d_lde, uint32_t base_cols,
+                          uint32_t log_n, uint32_t log_b, uint32_t log_tm, void *d_leaves, int *done);   // hash_kernels.hip
 int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
                           void *d_transposed, void *d_leaves, int *done);   // hash_kernels.hip
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field
