@@ -137,6 +137,12 @@ int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const vo
                            uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
                            void *d_lde);
 
+/* Hasher::hash(&[u8]) for the byte hashers (crypto/src/hash/blake/mod.rs:29-31,80-84; sha/mod.rs:26-28): `count` byte strings
+ * of len_bytes each, message i at d_msgs + i * stride_bytes (stride a multiple of 8, the bytes between len_bytes and the
+ * next multiple of 8 zero).  The Rescue hashers' hash(bytes) is hash_elements over the string's 7-byte chunks (a host-side
+ * conversion, rp64_256/mod.rs:123-178), so they return WF_ERR_UNSUPPORTED here. */
+int wf_hash_bytes_batch(wf_ctx *ctx, int hash, const void *d_msgs, uint64_t count, uint64_t stride_bytes, uint64_t len_bytes, void *d_out);
+
 /* ColMatrix::evaluate_columns_over (col_matrix.rs:230-243; the column-major LDE the reference's benches/row_matrix.rs
  * compares RowMatrix against): column k of d_out (at k * out_col_stride base elements) = fft::evaluate_poly_with_offset
  * of column k of d_polys; natural order, (n << log_blowup) elements each. */

@@ -357,3 +357,54 @@ def test_merge_many_on_every_hasher(wf, oracle, hname, hid):
         assert np.array_equal(hasher.merge_many(digs[i]), got[i])
     if hname != "RpJive64_256":
         assert np.array_equal(hasher.merge_many(digs[0][:2]), hasher.merge(digs[0][:2]))
+
+
+def _chunk_elements(data, modulus):
+    """test-side restatement of the Rescue byte -> element rule (rp64_256/mod.rs:123-160): canonical integers"""
+    out = []
+    n = -(-len(data) // 7)
+    for k in range(n):
+        ch = data[7 * k:7 * k + 7]
+        v = int.from_bytes(ch, "little") + ((1 << (8 * len(ch))) if k == n - 1 else 0)
+        out.append(v % modulus)
+    return out
+
+
+def test_hasher_hash_bytes(wf, oracle):
+    """Hasher::hash(&[u8]) (crypto/src/hash/mod.rs:33-35) on every hasher.  Byte hashers: every length 0..300 (block, chunk and
+    rate-block boundaries; partial words) against the LLVM-pinned BLAKE3 restatement / hashlib's SHA3; Rescue hashers: the
+    sponge over the 7-byte chunks, plus the reference's hash_padding properties (rescue tests.rs:162-182)."""
+    import hashlib
+    ctx, crypto, prover, fields = wf
+    rng = np.random.default_rng(21)
+    for n in list(range(0, 80)) + [127, 128, 129, 135, 136, 137, 271, 272, 273, 300, 1023, 1024, 1025, 2048, 3000]:
+        msg = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert crypto.Blake3_256.hash(msg).tobytes() == oracle.blake3(msg), n
+        assert crypto.Blake3_192.hash(msg).tobytes() == oracle.blake3(msg)[:24] + bytes(8), n
+        assert crypto.Sha3_256.hash(msg).tobytes() == hashlib.sha3_256(msg).digest(), n
+    batch = [rng.integers(0, 256, 41, dtype=np.uint8).tobytes() for _ in range(70)]
+    got = crypto.Blake3_256.hash(batch)
+    assert all(got[i].tobytes() == oracle.blake3(batch[i]) for i in range(70))
+    assert crypto.Blake3_256.hash(bytes([1])).tobytes() == oracle.blake3(bytes([1]))       # crypto/src/merkle/mod.rs:72 doc example
+    for hasher, hid, f in ((crypto.Rp64_256, 1, fields.f64), (crypto.RpJive64_256, 3, fields.f64), (crypto.Rp62_248, 4, fields.f62)):
+        for n in (0, 1, 3, 6, 7, 8, 13, 14, 28, 29, 55, 56):                                  # up to 8 chunks: one rule for all three
+            msg = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+            want = oracle.hash_elements(hid, f.pack([f.new(v) for v in _chunk_elements(msg, f.M)])) if hid != 4 else None
+            got = hasher.hash(msg)
+            if hid != 4:
+                assert np.array_equal(got, want), (hid, n)
+            else:
+                assert np.array_equal(got, hasher.hash_elements(f.pack([f.new(v) for v in _chunk_elements(msg, f.M)])))
+        pairs = [([1, 2, 3], [1, 2, 3, 0]), ([1, 2, 3, 4, 5, 6], [1, 2, 3, 4, 5, 6, 0]), ([1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7, 0]),
+                 ([1, 2, 3, 4, 5, 6, 7, 0, 0], [1, 2, 3, 4, 5, 6, 7, 0, 0, 0, 0])]
+        for a, b in pairs:
+            assert not np.array_equal(hasher.hash(bytes(a)), hasher.hash(bytes(b)))
+    # longer strings: Rp64 / RpJive keep the chunk-index rule, Rp62_248 the position-based one (rp62_248/mod.rs:119)
+    msg = rng.integers(0, 256, 100, dtype=np.uint8).tobytes()
+    assert np.array_equal(crypto.Rp64_256.hash(msg), oracle.hash_elements(1, fields.f64.pack([fields.f64.new(v) for v in _chunk_elements(msg, fields.f64.M)])))
+    with pytest.raises(ValueError):
+        crypto.Rp62_248.hash(msg)                                                            # 100 = 14 * 7 + 2: the reference panics
+    m70 = rng.integers(0, 256, 70, dtype=np.uint8).tobytes()
+    f62 = fields.f62
+    verbatim = [int.from_bytes(m70[7 * k:7 * k + 7], "little") for k in range(10)]
+    assert np.array_equal(crypto.Rp62_248.hash(m70), crypto.Rp62_248.hash_elements(f62.pack([f62.new(v) for v in verbatim])))

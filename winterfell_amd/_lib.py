@@ -48,6 +48,7 @@ _PROTOS = {
     "wf_merkle_build": [_vp, _int, _vp, _u64, _vp],
     "wf_hash_merge_batch": [_vp, _int, _vp, _u64, _vp],
     "wf_hash_elements_batch": [_vp, _int, _int, _vp, _u64, _u64, _u32, _vp],
+    "wf_hash_bytes_batch": [_vp, _int, _vp, _u64, _u64, _u64, _vp],
     "wf_hash_merge_many_batch": [_vp, _int, _vp, _u64, _u32, _vp],
     "wf_hash_merge_with_int_batch": [_vp, _int, _vp, _u64, _u64, _vp],
     "wf_grind": [_vp, _int, _vp, _u32, _u64, _u64, ctypes.POINTER(ctypes.c_uint64)],

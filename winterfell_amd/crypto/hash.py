@@ -49,6 +49,24 @@ class _Hasher:
 
 
     @classmethod
+    def hash(cls, data, ctx=None):
+        """Hasher::hash(&[u8]) (crypto/src/hash/mod.rs:33-35): digest of a byte string; a list of equal-length byte strings
+        is hashed as one batch -> (k, 32)."""
+        ctx = ctx or default_context()
+        single = isinstance(data, (bytes, bytearray, memoryview))
+        msgs = [bytes(data)] if single else [bytes(m) for m in data]
+        n = len(msgs[0]) if msgs else 0
+        assert all(len(m) == n for m in msgs), "a batch hashes strings of one length"
+        stride = max(8, -(-n // 8) * 8)
+        buf = np.zeros((len(msgs), stride), dtype=np.uint8)
+        for i, m in enumerate(msgs):
+            buf[i, :n] = np.frombuffer(m, dtype=np.uint8)
+        d_out = ctx.empty_u8(max(len(msgs), 1), 32)
+        ctx.call("wf_hash_bytes_batch", cls.HASH_ID, ptr(ctx.to_device(buf)), len(msgs), stride, n, ptr(d_out))
+        out = ctx.to_host(d_out)[:len(msgs)]
+        return out[0] if single else out
+
+    @classmethod
     def merge_many(cls, values, ctx=None):
         """Hasher::merge_many(&[Digest]) (crypto/src/hash/mod.rs:39-41) — values: (k, 32) digests -> (32,), or (n, k, 32)
         for n independent merges -> (n, 32).  Byte hashers hash the concatenated digest bytes (24 per digest for
@@ -102,9 +120,39 @@ class Sha3_256(_Hasher):
     HASH_ID = WF_HASH_SHA3_256
 
 
+def _bytes_to_elements(data, field, strict_index=True):
+    """The Rescue hashers' byte -> element rule (rp64_256/mod.rs:123-160, rp64_256_jive/mod.rs:119-164, rp62_248/mod.rs:97-141):
+    7-byte little-endian chunks, the LAST chunk zero-padded with a 1 byte appended after its data.  Rp62_248 decides "last"
+    by the position inside the current rate block rather than by the chunk index (rp62_248/mod.rs:119): for inputs of more
+    than 8 chunks its final chunk is taken verbatim (and a short one panics in copy_from_slice) — reproduced with
+    strict_index=False."""
+    data = bytes(data)
+    chunks = [data[i:i + 7] for i in range(0, len(data), 7)]
+    out, pos = [], 0
+    for index, ch in enumerate(chunks):
+        last = (index if strict_index else pos) >= len(chunks) - 1
+        if last:
+            buf = ch + b"\x01" + bytes(7 - len(ch))
+        else:
+            if len(ch) != 7:
+                raise ValueError("source slice length (%d) does not match destination slice length (7)" % len(ch))
+            buf = ch + b"\x00"
+        out.append(field.new(int.from_bytes(buf, "little")))
+        pos = (pos + 1) % 8
+    return field.pack(out) if out else np.zeros(0, dtype=np.uint64)
+
+
 class Rp64_256(_Hasher):
     """crypto::hash::Rp64_256 (crypto/src/hash/rescue/rp64_256/mod.rs:123-257)."""
     HASH_ID = WF_HASH_RP64_256
+
+    @classmethod
+    def hash(cls, data, ctx=None):
+        """Hasher::hash (mod.rs:123-178): the sponge over the string's 7-byte chunks — the same absorb / padding as
+        hash_elements over those elements (the conversion is host logic, the permutations run on the device)."""
+        if not isinstance(data, (bytes, bytearray, memoryview)):
+            return np.stack([cls.hash(m, ctx) for m in data])
+        return cls.hash_elements(_bytes_to_elements(data, fields.f64), ctx)
 
     # merge_many: hash_elements over the digests' elements (rp64_256/mod.rs:194-196) — the base class's library call
 
@@ -128,6 +176,13 @@ class Rp62_248(_Hasher):
     @classmethod
     def hash_elements(cls, elements, ctx=None, field=fields.f62):
         return super().hash_elements(elements, ctx, field)
+
+    @classmethod
+    def hash(cls, data, ctx=None):
+        """Hasher::hash (rp62_248/mod.rs:97-153), including its position-based last-chunk test."""
+        if not isinstance(data, (bytes, bytearray, memoryview)):
+            return np.stack([cls.hash(m, ctx) for m in data])
+        return cls.hash_elements(_bytes_to_elements(data, fields.f62, strict_index=False), ctx)
 
     @staticmethod
     def digest_as_bytes(digest):

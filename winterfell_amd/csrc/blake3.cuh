@@ -164,9 +164,11 @@ __device__ __forceinline__ void hash_words(const W &w, uint32_t nwords, uint32_t
 // FB: callable  fetch(block_index, nwords_valid, m)  that fills the 16 message words of 64-byte block `block_index` of the
 // whole message (words past nwords_valid zero).  Same chunk / tree structure as above; lets a wavefront bring a block of
 // 64 rows in cooperatively (hash_kernels.hip, wide rows) instead of every lane walking its own row.
+// tail_cut (0..3): bytes by which the message is shorter than its last word (byte-string messages, Hasher::hash); the
+// fetcher still delivers whole words with the missing bytes zero, only the last block's length changes.
 template <class FB>
 __device__ __forceinline__ void chunk_blocks(const FB &fetch, uint32_t blk0, uint32_t nwords_chunk, uint32_t chunk_counter, bool root,
-                                             uint32_t (&out)[8]) {
+                                             uint32_t (&out)[8], uint32_t tail_cut = 0) {
     uint32_t cv[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) cv[i] = iv(i);
@@ -175,7 +177,8 @@ __device__ __forceinline__ void chunk_blocks(const FB &fetch, uint32_t blk0, uin
         uint32_t m[16];
         const uint32_t left = nwords_chunk - blk * 16;
         fetch(blk0 + blk, left >= 16 ? 16u : left, m);
-        const uint32_t block_len = left >= 16 ? 64u : left * 4u;
+        uint32_t block_len = left >= 16 ? 64u : left * 4u;
+        if (blk + 1 == nblocks) block_len -= tail_cut;
         uint32_t flags = (blk == 0 ? CHUNK_START : 0u) | (blk + 1 == nblocks ? CHUNK_END : 0u);
         if (root && blk + 1 == nblocks) flags |= ROOT;
         uint32_t o[8];
@@ -188,9 +191,9 @@ __device__ __forceinline__ void chunk_blocks(const FB &fetch, uint32_t blk0, uin
 }
 
 template <class FB>
-__device__ __forceinline__ void hash_blocks(const FB &fetch, uint32_t nwords, uint32_t (&out)[8]) {
+__device__ __forceinline__ void hash_blocks(const FB &fetch, uint32_t nwords, uint32_t (&out)[8], uint32_t tail_cut = 0) {
     if (nwords <= 256) {
-        chunk_blocks(fetch, 0, nwords, 0, true, out);
+        chunk_blocks(fetch, 0, nwords, 0, true, out, tail_cut);
         return;
     }
     const uint32_t nchunks = (nwords + 255) / 256;
@@ -212,7 +215,7 @@ __device__ __forceinline__ void hash_blocks(const FB &fetch, uint32_t nwords, ui
         sp++;
     }
     const uint32_t last = nchunks - 1;
-    chunk_blocks(fetch, last * 16, nwords - last * 256, last, false, cv);
+    chunk_blocks(fetch, last * 16, nwords - last * 256, last, false, cv, tail_cut);
     while (sp > 0) {
         sp--;
         uint32_t l[8], o[8];

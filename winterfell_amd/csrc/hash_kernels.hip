@@ -32,6 +32,20 @@ struct Digest {
 struct HBlake3 {
     static constexpr bool WIDE = true;               // rows of >= 64 bytes: wave-cooperative block loads (hash_rows_wide_kernel)
     static constexpr int WIDE_BW = 8;                // 64-bit words per message block
+    static constexpr bool BYTES = true;              // Hasher::hash(&[u8]) supported on the device
+    // Hasher::hash (blake/mod.rs:29-31): p = the message as zero-padded 64-bit words
+    static __device__ __forceinline__ void hash_bytes(const uint64_t *p, uint64_t nbytes, uint32_t (&out)[8]) {
+        const uint32_t nwords = (uint32_t)((nbytes + 3) / 4);
+        auto fetch = [&](uint32_t blk, uint32_t nvalid, uint32_t (&m)[16]) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint64_t v = (uint32_t)(2 * i) < nvalid ? p[blk * 8 + i] : 0;
+                m[2 * i] = (uint32_t)v;
+                m[2 * i + 1] = (uint32_t)(2 * i + 1) < nvalid ? (uint32_t)(v >> 32) : 0u;
+            }
+        };
+        b3::hash_blocks(fetch, nwords, out, (uint32_t)(nwords * 4 - nbytes));
+    }
     template <class FB>
     static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
         auto fetch = [&](uint32_t blk, uint32_t, uint32_t (&m)[16]) {
@@ -87,6 +101,11 @@ struct HBlake3 {
 struct HBlake3_192 {
     static constexpr bool WIDE = true;
     static constexpr int WIDE_BW = 8;
+    static constexpr bool BYTES = true;
+    static __device__ __forceinline__ void hash_bytes(const uint64_t *p, uint64_t nbytes, uint32_t (&out)[8]) {
+        HBlake3::hash_bytes(p, nbytes, out);
+        out[6] = out[7] = 0;
+    }
     template <class FB>
     static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
         HBlake3::hash_wide(fetch64, nelem, out);
@@ -140,6 +159,7 @@ struct HBlake3_192 {
 // RpJive64_256 (crypto/src/hash/rescue/rp64_256_jive/mod.rs): ElementDigest like Rp64_256, width-8 permutation
 struct HRpJive {
     static constexpr bool WIDE = false;
+    static constexpr bool BYTES = false;             // hash(bytes) = hash_elements over the 7-byte chunks (host conversion)
     static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
     typedef rcoop::CoopRpJive Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;      // as for Rp64_256: one full-width level per launch
@@ -196,6 +216,7 @@ struct HRpJive {
 // Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs): four f62 words per digest, defined over f62 only
 struct HRp62 {
     static constexpr bool WIDE = false;
+    static constexpr bool BYTES = false;             // hash(bytes) = hash_elements over the 7-byte chunks (host conversion)
     static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
     typedef rcoop::CoopRp62 Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;
@@ -253,6 +274,22 @@ struct HRp62 {
 struct HSha3 {
     static constexpr bool WIDE = true;
     static constexpr int WIDE_BW = 17;               // the 136-byte rate
+    static constexpr bool BYTES = true;
+    // Hasher::hash (sha/mod.rs:26-28)
+    static __device__ __forceinline__ void hash_bytes(const uint64_t *p, uint64_t nbytes, uint32_t (&out)[8]) {
+        const uint32_t nwords = (uint32_t)((nbytes + 7) / 8);
+        auto fetch = [&](uint32_t blk, uint64_t (&m)[17]) {
+#pragma unroll
+            for (int i = 0; i < 17; i++) m[i] = blk * 17 + i < nwords ? p[blk * 17 + i] : 0;
+        };
+        uint64_t d[4];
+        k3::sha3_256_bytes(fetch, nbytes, d);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            out[2 * i] = (uint32_t)d[i];
+            out[2 * i + 1] = (uint32_t)(d[i] >> 32);
+        }
+    }
     template <class FB>
     static __device__ __forceinline__ void hash_wide(const FB &fetch64, uint32_t nelem, uint32_t (&out)[8]) {
         uint64_t d[4];
@@ -304,6 +341,7 @@ struct HSha3 {
 
 struct HRp64 {
     static constexpr bool WIDE = false;
+    static constexpr bool BYTES = false;             // hash(bytes) = hash_elements over the 7-byte chunks (host conversion)
     static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
     typedef rcoop::CoopRp64 Coop;
     // a Rescue merge is ~6400 modmuls (0.2 ms of one wave): the nearly empty upper levels of a multi-level workgroup
@@ -892,6 +930,35 @@ extern "C" int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degre
                             void *d_leaves) {
     return hash_rows_impl(ctx, hash, field, ext_degree, d_rows, num_rows, row_width, elems_per_row, num_partitions,
                           hash_rate, d_leaves);
+}
+
+namespace {
+template <class H>
+__global__ __launch_bounds__(256) void hash_bytes_kernel(const uint64_t *msgs, uint64_t count, uint64_t stride_words, uint64_t nbytes, void *out) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t d[8];
+    if constexpr (H::BYTES) H::hash_bytes(msgs + gid * stride_words, nbytes, d);
+    store_digest(out, gid, d);
+}
+}  // namespace
+
+extern "C" int wf_hash_bytes_batch(wf_ctx *ctx, int hash, const void *d_msgs, uint64_t count, uint64_t stride_bytes, uint64_t len_bytes,
+                                   void *d_out) {
+    if (!ctx || !d_out || (count && len_bytes && !d_msgs)) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (hash != WF_HASH_BLAKE3_256 && hash != WF_HASH_BLAKE3_192 && hash != WF_HASH_SHA3_256) return WF_ERR_UNSUPPORTED;
+    if (stride_bytes % 8 || stride_bytes < ((len_bytes + 7) / 8) * 8 || len_bytes >= (1ull << 32)) return WF_ERR_INVALID_ARG;
+    if (count == 0) return WF_OK;
+    const uint64_t blocks = (count + 255) / 256;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        hipLaunchKernelGGL(hash_bytes_kernel<decltype(h)>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, (const uint64_t *)d_msgs, count,
+                           stride_bytes / 8, len_bytes, d_out);
+        return (int)WF_OK;
+    }));
+    WF_HIP(hipGetLastError());
+    return WF_OK;
 }
 
 extern "C" int wf_hash_columns(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_cols, uint32_t num_cols,

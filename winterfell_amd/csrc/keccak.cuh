@@ -90,4 +90,30 @@ __device__ __forceinline__ void sha3_256_blocks(const FB &fetch, uint32_t n, uin
     for (int i = 0; i < 4; i++) digest[i] = st[i];
 }
 
+// SHA3-256 of an nbytes-long byte string delivered as 64-bit little-endian words by fetch(blk, m) (17 words per rate
+// block, bytes past the message zero): the domain/pad byte 0x06 lands at byte nbytes of the message
+template <class FB>
+__device__ __forceinline__ void sha3_256_bytes(const FB &fetch, uint64_t nbytes, uint64_t (&digest)[4]) {
+    uint64_t st[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) st[i] = 0;
+    const uint32_t pad_word = (uint32_t)(nbytes / 8), pad_shift = (uint32_t)(nbytes % 8) * 8;
+    const uint32_t last = pad_word / 17, left = pad_word - last * 17;
+    for (uint32_t blk = 0; blk <= last; blk++) {
+        uint64_t m[17];
+        fetch(blk, m);
+#pragma unroll
+        for (int k = 0; k < 17; k++) st[k] ^= m[k];
+        if (blk == last) {
+#pragma unroll
+            for (int k = 0; k < 17; k++)
+                if ((uint32_t)k == left) st[k] ^= 0x06ull << pad_shift;
+            st[16] ^= 0x8000000000000000ull;
+        }
+        f1600(st);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) digest[i] = st[i];
+}
+
 }  // namespace k3
