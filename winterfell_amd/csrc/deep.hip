@@ -47,13 +47,22 @@ struct Elem {
     T v[D];
 };
 
-// base given either by value (src == nullptr) or as entry `src_k` of another table (the recursion's b^1024)
+template <class T, int D>
+struct Elems4 {
+    Elem<T, D> e[4];
+};
+
+// base given either by value (src == nullptr; workgroup g of the launch takes bases.e[g] and writes table g, so the tables of
+// up to four points cost ONE chain of sequential squarings instead of four) or as entry `src_k` of another table (the
+// recursion's b^1024)
 template <class F, int D>
-__global__ __launch_bounds__(256) void pows_kernel(Elem<typename F::T, D> base, const typename F::T *src, int src_k,
-                                                   typename F::T one, typename F::T *out) {
+__global__ __launch_bounds__(256) void pows_kernel(Elems4<typename F::T, D> bases, const typename F::T *src, int src_k,
+                                                   typename F::T one, typename F::T *out, uint64_t out_stride) {
     typedef typename F::T T;
     __shared__ T sq[NPOW][D];
     const int t = threadIdx.x;
+    const Elem<T, D> base = bases.e[blockIdx.x];
+    out += blockIdx.x * out_stride;
     if (t == 0) {
         T cur[D], nxt[D];
 #pragma unroll
@@ -177,6 +186,45 @@ __global__ __launch_bounds__(64) void eval_combine_kernel(const typename F::T *p
     for (uint32_t s = nseg; s-- > 0;) horner_step<F, D, D>(acc, X, src + (uint64_t)s * D);
 #pragma unroll
     for (int d = 0; d < D; d++) out[(uint64_t)gid * D + d] = acc[d];
+}
+
+// the same recombination for MANY segments (up to 1024): one workgroup per (point, column); lane t runs Horner over its
+// C = nseg / lanes consecutive partials with X = x^seg_len, lifts the result by X^(t * C) (product of the table's
+// x^(2^k) entries over the set bits of t * C) and the workgroup sums.  Short segments keep the per-lane Horner chain of
+// eval_partial_kernel at 4 steps; the 64-segment limit of the sequential kernel made it 64.
+template <class F, int D>
+__global__ __launch_bounds__(256) void eval_combine_wide_kernel(const typename F::T *partials, uint32_t cols, uint32_t log_nseg, uint32_t log_seg,
+                                                                const typename F::T *pw, uint64_t pw_stride, typename F::T one, typename F::T *out) {
+    typedef typename F::T T;
+    __shared__ T buf[256][D];
+    const uint32_t gid = blockIdx.x, p = gid / cols, t = threadIdx.x;
+    Pows<F, D> P{pw + p * pw_stride};
+    const uint32_t log_thr = log_nseg < 8 ? log_nseg : 8, log_c = log_nseg - log_thr, C = 1u << log_c;
+    T acc[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) acc[d] = F::zero();
+    if (t < (1u << log_thr)) {
+        T X[D];
+        P.pow2(log_seg, X);
+        const T *src = partials + ((uint64_t)gid << log_nseg) * D + (uint64_t)t * C * D;
+        for (uint32_t s = C; s-- > 0;) horner_step<F, D, D>(acc, X, src + (uint64_t)s * D);
+        const uint32_t e = t << log_c;                       // lift by X^e = x^(e * 2^log_seg)
+        for (uint32_t k = 0; k < log_nseg; k++) {
+            if ((e >> k) & 1) {
+                T f[D], tmp[D];
+                P.pow2(log_seg + k, f);
+                F::template ext_mul<D>(acc, f, tmp);
+#pragma unroll
+                for (int d = 0; d < D; d++) acc[d] = tmp[d];
+            }
+        }
+    }
+    (void)one;
+    block_sum<F, D>(acc, buf);
+    if (t == 0) {
+#pragma unroll
+        for (int d = 0; d < D; d++) out[(uint64_t)gid * D + d] = acc[d];
+    }
 }
 
 // S[j] = sum_i cc_i * T_i[j]   (main: base-field columns, k.mul_base(b); aux / quot: columns over E, full products)
@@ -318,9 +366,22 @@ struct Deep {
     static constexpr size_t PW_WORDS = (size_t)(NPOW + NTBL) * D;
 
     static int make_pows(wf_ctx *ctx, const T *base, const T *src, int src_k, T *d_out) {
-        Elem<T, D> b;
-        for (int d = 0; d < D; d++) b.v[d] = base ? base[d] : 0;
-        hipLaunchKernelGGL((pows_kernel<F, D>), dim3(1), dim3(256), 0, ctx->stream, b, src, src_k, HF::to_internal(HF::from_u64(1)), d_out);
+        Elems4<T, D> b;
+        memset(&b, 0, sizeof(b));
+        for (int d = 0; d < D; d++) b.e[0].v[d] = base ? base[d] : 0;
+        hipLaunchKernelGGL((pows_kernel<F, D>), dim3(1), dim3(256), 0, ctx->stream, b, src, src_k, HF::to_internal(HF::from_u64(1)), d_out,
+                           (uint64_t)PW_WORDS);
+        WF_HIP(hipGetLastError());
+        return WF_OK;
+    }
+    // tables of `count` <= 4 points (count * D words at `bases`) in one launch, table g at d_out + g * PW_WORDS
+    static int make_pows_multi(wf_ctx *ctx, const T *bases, uint32_t count, T *d_out) {
+        Elems4<T, D> b;
+        memset(&b, 0, sizeof(b));
+        for (uint32_t g = 0; g < count; g++)
+            for (int d = 0; d < D; d++) b.e[g].v[d] = bases[g * D + d];
+        hipLaunchKernelGGL((pows_kernel<F, D>), dim3(count), dim3(256), 0, ctx->stream, b, (const T *)nullptr, 0, HF::to_internal(HF::from_u64(1)),
+                           d_out, (uint64_t)PW_WORDS);
         WF_HIP(hipGetLastError());
         return WF_OK;
     }
@@ -381,19 +442,24 @@ struct Deep {
                            const void *h_points, uint32_t num_points, void *h_out) {
         // segments: enough workgroups to fill the chip, at least 256 coefficients each
         const uint32_t log_thr = log_n < 8 ? log_n : 8;
-        // (the recombination kernel walks a column's segments sequentially: at most 64 of them)
+        // segments of >= 1024 coefficients (4 Horner steps per lane), up to 1024 of them per column, ~4096 workgroups in all
         uint32_t log_seg = log_n;
-        while (log_seg > 12 && log_n - log_seg < 6 && ((uint64_t)num_cols << (log_n - log_seg)) < 2048) log_seg--;
+        while (log_seg > 10 && log_n - log_seg < 10 && ((uint64_t)num_cols << (log_n - log_seg)) < 4096) log_seg--;
         if (log_seg < log_thr) log_seg = log_thr;
         const uint32_t nseg = 1u << (log_n - log_seg);
         void *tmp;
         const size_t words = (size_t)num_points * PW_WORDS + (size_t)num_points * num_cols * nseg * D + (size_t)num_points * num_cols * D;
         WF_TRY(wf_scratch(ctx, 1, words * sizeof(T), &tmp));
         T *pw = (T *)tmp, *partials = pw + (size_t)num_points * PW_WORDS, *d_out = partials + (size_t)num_points * num_cols * nseg * D;
-        for (uint32_t p = 0; p < num_points; p++) {
-            T x[D];
-            WF_TRY(load_elem(h_points, p, x));
-            WF_TRY(make_pows(ctx, x, nullptr, 0, pw + p * PW_WORDS));
+        for (uint32_t p = 0; p < num_points; p += 4) {
+            T xs[4 * D];
+            const uint32_t cnt = num_points - p < 4 ? num_points - p : 4;
+            for (uint32_t g = 0; g < cnt; g++) {
+                T x[D];
+                WF_TRY(load_elem(h_points, p + g, x));
+                for (int d = 0; d < D; d++) xs[g * D + d] = x[d];
+            }
+            WF_TRY(make_pows_multi(ctx, xs, cnt, pw + p * PW_WORDS));
         }
         const T *polys = (const T *)d_polys;
         wf_prof_begin(ctx, "poly_eval_at");
@@ -411,8 +477,12 @@ struct Deep {
             }
         }
         const uint32_t total = num_points * num_cols;
-        hipLaunchKernelGGL((eval_combine_kernel<F, D>), dim3((total + 63) / 64), dim3(64), 0, ctx->stream, (const T *)partials, num_cols, nseg,
-                           log_seg, num_points, (const T *)pw, (uint64_t)PW_WORDS, d_out);
+        if (nseg > 16)
+            hipLaunchKernelGGL((eval_combine_wide_kernel<F, D>), dim3(total), dim3(256), 0, ctx->stream, (const T *)partials, num_cols,
+                               log_n - log_seg, log_seg, (const T *)pw, (uint64_t)PW_WORDS, HF::to_internal(HF::from_u64(1)), d_out);
+        else
+            hipLaunchKernelGGL((eval_combine_kernel<F, D>), dim3((total + 63) / 64), dim3(64), 0, ctx->stream, (const T *)partials, num_cols, nseg,
+                               log_seg, num_points, (const T *)pw, (uint64_t)PW_WORDS, d_out);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
         WF_HIP(hipMemcpyAsync(h_out, d_out, (size_t)total * D * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
