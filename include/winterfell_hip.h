@@ -78,8 +78,13 @@ int wf_last_hip_error(wf_ctx *ctx);
 int wf_prof_enable(wf_ctx *ctx, int on);
 int wf_prof_collect(wf_ctx *ctx, char *h_buf, size_t buf_len);
 
+/* Device memory for the caller's buffers.  wf_free does not synchronise: blocks go to a per-context pool and are handed out
+ * again by later wf_malloc calls — safe because everything a context does is ordered on its stream (a buffer shared with
+ * another stream must be synchronised by the caller before it is freed).  wf_ctx_trim returns the cached blocks to the
+ * driver; wf_ctx_destroy does so implicitly. */
 int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr);
 int wf_free(wf_ctx *ctx, void *d_ptr);
+int wf_ctx_trim(wf_ctx *ctx);
 int wf_memcpy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wf_memcpy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes); /* synchronises */
 int wf_memcpy_d2d(wf_ctx *ctx, void *d_dst, const void *d_src, size_t bytes);

@@ -28,6 +28,7 @@ _PROTOS = {
     "wf_prof_collect": [_vp, ctypes.c_char_p, ctypes.c_size_t],
     "wf_malloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
     "wf_free": [_vp, _vp],
+    "wf_ctx_trim": [_vp],
     "wf_memcpy_h2d": [_vp, _vp, _vp, ctypes.c_size_t],
     "wf_memcpy_d2h": [_vp, _vp, _vp, ctypes.c_size_t],
     "wf_memcpy_d2d": [_vp, _vp, _vp, ctypes.c_size_t],

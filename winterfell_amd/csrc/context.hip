@@ -50,6 +50,7 @@ extern "C" int wf_ctx_destroy(wf_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (void *p : ctx->owned) (void)hipFree(p);
+    for (auto &kv : ctx->pool_free) (void)hipFree(kv.second);
     for (int i = 0; i < 3; i++)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     for (auto &r : ctx->prof) {
@@ -63,8 +64,9 @@ extern "C" int wf_ctx_destroy(wf_ctx *ctx) {
 
 extern "C" int wf_ctx_set_stream(wf_ctx *ctx, void *hip_stream) {
     if (!ctx) return WF_ERR_INVALID_ARG;
+    if ((hipStream_t)hip_stream == ctx->stream) return WF_OK;
+    (void)hipStreamSynchronize(ctx->stream);       // cached pool blocks are ordered on the old stream
     if (ctx->own_stream) {
-        (void)hipStreamSynchronize(ctx->stream);
         (void)hipStreamDestroy(ctx->stream);
         ctx->own_stream = false;
     }
@@ -86,17 +88,71 @@ extern "C" int wf_ctx_sync(wf_ctx *ctx) {
 
 extern "C" int wf_last_hip_error(wf_ctx *ctx) { return ctx ? ctx->last_hip_error : 0; }
 
+// size classes: multiples of 512 B below 1 MiB, of 2 MiB above (what hipMalloc rounds to anyway)
+static size_t pool_round(size_t bytes) {
+    if (bytes == 0) bytes = 1;
+    const size_t g = bytes < (1u << 20) ? 512 : (2u << 20);
+    return (bytes + g - 1) / g * g;
+}
+
+static void pool_release_cached(wf_ctx *ctx) {
+    if (ctx->pool_free.empty()) return;
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto &kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    ctx->pool_free_bytes = 0;
+}
+
 extern "C" int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr) {
     if (!ctx || !d_ptr) return WF_ERR_INVALID_ARG;
+    const size_t want = pool_round(bytes);
+    // best fit among the cached blocks, wasting at most a quarter of the block
+    auto it = ctx->pool_free.lower_bound(want);
+    if (it != ctx->pool_free.end() && it->first <= want + want / 4) {
+        *d_ptr = it->second;
+        ctx->pool_live[it->second] = it->first;
+        ctx->pool_free_bytes -= it->first;
+        ctx->pool_free.erase(it);
+        return WF_OK;
+    }
     WF_HIP(hipSetDevice(ctx->device));
-    WF_HIP(hipMalloc(d_ptr, bytes ? bytes : 1));
+    hipError_t e = hipMalloc(d_ptr, want);
+    if (e != hipSuccess) {                      // out of memory: give the cached blocks back to the driver and retry once
+        (void)hipGetLastError();
+        pool_release_cached(ctx);
+        WF_HIP(hipMalloc(d_ptr, want));
+    }
+    ctx->pool_live[*d_ptr] = want;
     return WF_OK;
 }
 
 extern "C" int wf_free(wf_ctx *ctx, void *d_ptr) {
     if (!ctx) return WF_ERR_INVALID_ARG;
-    WF_HIP(hipStreamSynchronize(ctx->stream));
-    WF_HIP(hipFree(d_ptr));
+    if (!d_ptr) return WF_OK;
+    auto it = ctx->pool_live.find(d_ptr);
+    if (it == ctx->pool_live.end()) {           // not ours (or already freed): the old behaviour
+        WF_HIP(hipStreamSynchronize(ctx->stream));
+        WF_HIP(hipFree(d_ptr));
+        return WF_OK;
+    }
+    const size_t sz = it->second;
+    ctx->pool_live.erase(it);
+    ctx->pool_free.emplace(sz, d_ptr);
+    ctx->pool_free_bytes += sz;
+    // keep at most 64 GiB cached (of 288): beyond that return the largest blocks to the driver
+    while (ctx->pool_free_bytes > (64ull << 30) && !ctx->pool_free.empty()) {
+        auto big = std::prev(ctx->pool_free.end());
+        WF_HIP(hipStreamSynchronize(ctx->stream));
+        WF_HIP(hipFree(big->second));
+        ctx->pool_free_bytes -= big->first;
+        ctx->pool_free.erase(big);
+    }
+    return WF_OK;
+}
+
+extern "C" int wf_ctx_trim(wf_ctx *ctx) {
+    if (!ctx) return WF_ERR_INVALID_ARG;
+    pool_release_cached(ctx);
     return WF_OK;
 }
 

@@ -64,6 +64,13 @@ struct wf_ctx {
     };
     std::vector<ProfRec> prof;
 
+    // wf_malloc / wf_free: a stream-ordered caching pool.  Every kernel and copy of a context is enqueued on ctx->stream, so a
+    // block freed by the caller can be handed to the next wf_malloc WITHOUT synchronising: whatever still reads it was enqueued
+    // before whatever will write it.  (hipFree is a device-wide synchronisation; a proof allocates ~40 buffers.)
+    std::multimap<size_t, void *> pool_free;       // size -> block
+    std::map<void *, size_t> pool_live;            // block -> its (rounded) size
+    size_t pool_free_bytes = 0;
+
     // scratch buffers (grow-only)
     void *scratch[3] = {nullptr, nullptr, nullptr};
     size_t scratch_bytes[3] = {0, 0, 0};
