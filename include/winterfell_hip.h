@@ -226,7 +226,12 @@ int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t 
  * reference ships as examples are built in: */
 enum {
     WF_AIR_FIB_SMALL = 0,   /* examples/src/fibonacci/fib_small/air.rs (2 columns, any field)                         */
-    WF_AIR_RESCUE = 1       /* examples/src/rescue/air.rs + rescue.rs (4 columns, 9 periodic columns, f128 only)      */
+    WF_AIR_RESCUE = 1,      /* examples/src/rescue/air.rs + rescue.rs (4 columns, 9 periodic columns, f128 only)      */
+    WF_AIR_FIB8 = 2,        /* examples/src/fibonacci/fib8/air.rs (2 columns, 8 terms per step, ce_blowup 2)          */
+    WF_AIR_MULFIB2 = 3,     /* examples/src/fibonacci/mulfib2/air.rs (2 columns, degree-2 constraints, ce_blowup 2)   */
+    WF_AIR_MULFIB8 = 4,     /* examples/src/fibonacci/mulfib8/air.rs (8 columns, degree 2, ce_blowup 2)               */
+    WF_AIR_VDF = 5,         /* examples/src/vdf/regular/air.rs (1 column, degree 3, ce_blowup 2)                      */
+    WF_AIR_VDF_EXEMPT = 6   /* examples/src/vdf/exempt/air.rs (the same with 2 transition exemptions)                 */
 };
 
 /* DefaultConstraintEvaluator::evaluate for a single-segment trace (prover/src/constraints/evaluator/default.rs:52-106,

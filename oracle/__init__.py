@@ -575,8 +575,9 @@ class GenericField:
         return out
 
     # ---- constraint evaluation (constraints_tmpl.inc) -----------------------------------------------------------
-    AIR_FIB_SMALL, AIR_RESCUE = 0, 1
-    AIR_SHAPES = {0: (2, 2, 0, 0), 1: (4, 4, 9, 16)}      # width, transition constraints, periodic columns, cycle
+    AIR_FIB_SMALL, AIR_RESCUE, AIR_FIB8, AIR_MULFIB2, AIR_MULFIB8, AIR_VDF, AIR_VDF_EXEMPT = 0, 1, 2, 3, 4, 5, 6
+    # width, transition constraints, periodic columns, cycle
+    AIR_SHAPES = {0: (2, 2, 0, 0), 1: (4, 4, 9, 16), 2: (2, 2, 0, 0), 3: (2, 2, 0, 0), 4: (8, 8, 0, 0), 5: (1, 1, 0, 0), 6: (1, 1, 0, 0)}
 
     def air_evaluate_transition(self, air, D, cur, nxt, periodic):
         """Air::evaluate_transition over degree-D elements; cur / nxt: width*D*W words, periodic: num_periodic*D*W."""
@@ -617,6 +618,29 @@ class GenericField:
     def fib_small_build_trace(self, n):
         out = np.empty((2, n * self.W), dtype=np.uint64)
         self._fn("fib_small_build_trace")(_u64(n), _ptr(out))
+        return out
+
+    def fib8_build_trace(self, n):
+        out = np.empty((2, n * self.W), dtype=np.uint64)
+        self._fn("fib8_build_trace")(_u64(n), _ptr(out))
+        return out
+
+    def mulfib2_build_trace(self, n):
+        out = np.empty((2, n * self.W), dtype=np.uint64)
+        self._fn("mulfib2_build_trace")(_u64(n), _ptr(out))
+        return out
+
+    def mulfib8_build_trace(self, n):
+        out = np.empty((8, n * self.W), dtype=np.uint64)
+        self._fn("mulfib8_build_trace")(_u64(n), _ptr(out))
+        return out
+
+    def vdf_build_trace(self, seed, n, exempt=False):
+        """f128 only: VdfProver::build_trace (regular / exempt) -> (1, n*W) words."""
+        assert self.name == "f128"
+        out = np.empty((1, n * self.W), dtype=np.uint64)
+        ps = self.pack([seed])
+        self._fn("vdf_build_trace")(_ptr(ps), _u64(n), ctypes.c_int(int(exempt)), _ptr(out))
         return out
 
     def rescue_build_trace(self, seed, iterations):

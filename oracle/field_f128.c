@@ -54,3 +54,21 @@ void or_f128_rescue_build_trace(const u128 seed[2], uint64_t iterations, u128 *t
         else st[2] = st[3] = 0;
     }
 }
+
+/* VdfProver::build_trace — examples/src/vdf/regular/prover.rs:30-41 and vdf/exempt/prover.rs:30-44 (exempt = 1: n - 1 real
+ * states, then the garbage value 123 in the last row).  state' = (state - 42)^INV_ALPHA, INV_ALPHA = (2p - 1) / 3
+ * (vdf/regular/mod.rs:30-32).  One column of n elements. */
+void or_f128_vdf_build_trace(const u128 *seed, uint64_t n, int exempt, u128 *trace) {
+    u128 ia = 0;
+    {   /* INV_ALPHA = 226854911280625642308916371969163307691 (no 128-bit literals in C) */
+        const char *dec = "226854911280625642308916371969163307691";
+        for (const char *c = dec; *c; c++) ia = ia * 10 + (u128)(*c - '0');
+    }
+    u128 st = *seed;
+    const uint64_t real = exempt ? n - 1 : n;
+    for (uint64_t i = 0; i < real; i++) {
+        trace[i] = st;
+        st = f128_exp(f128_sub(st, 42), ia);
+    }
+    if (exempt) trace[n - 1] = 123;
+}

@@ -27,10 +27,23 @@ def _setup(oracle, fields, air_mod, fname, air_id, n, blowup):
     if air_id == 0:
         trace = ofld.fib_small_build_trace(n)
         air = air_mod.FibSmall(n, fld.unpack(trace[1])[n - 1], blowup, fld)
-    else:
+    elif air_id == 1:
         trace = ofld.rescue_build_trace([42, 43], n // 16)
         t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
         air = air_mod.RescueAir(n, [t0[0], t1[0]], [t0[n - 1], t1[n - 1]], blowup)
+    elif air_id == 2:
+        trace = ofld.fib8_build_trace(n)
+        air = air_mod.Fib8(n, fld.unpack(trace[1])[n - 1], blowup, fld)
+    elif air_id == 3:
+        trace = ofld.mulfib2_build_trace(n)
+        air = air_mod.MulFib2(n, fld.unpack(trace[0])[n - 1], blowup, fld)
+    elif air_id == 4:
+        trace = ofld.mulfib8_build_trace(n)
+        air = air_mod.MulFib8(n, fld.unpack(trace[6])[n - 1], blowup, fld)
+    else:
+        ex = air_id == 6
+        trace = ofld.vdf_build_trace(987654321, n, exempt=ex)
+        air = air_mod.Vdf(n, 987654321, fld.unpack(trace[0])[n - 2 if ex else n - 1], blowup, exempt=ex, field=fld)
     return fld, ofld, trace, air
 
 
@@ -45,7 +58,11 @@ def _gpu_eval(ctx, prover, crypto, fld, trace, air, D, blowup, seed):
 
 
 CASES = [("f64", 0, 8, 1, 8), ("f64", 0, 64, 2, 8), ("f64", 0, 4096, 3, 2), ("f62", 0, 256, 2, 4), ("f128", 0, 128, 1, 8),
-         ("f128", 1, 32, 1, 8), ("f128", 1, 1024, 2, 4), ("f128", 1, 16, 2, 16)]
+         ("f128", 1, 32, 1, 8), ("f128", 1, 1024, 2, 4), ("f128", 1, 16, 2, 16),
+         # the other example AIRs of the reference (fib8, mulfib2, mulfib8, vdf regular / exempt)
+         ("f128", 2, 64, 1, 8), ("f64", 2, 1024, 2, 2), ("f128", 3, 128, 2, 8), ("f64", 3, 32, 3, 4), ("f62", 3, 64, 1, 8),
+         ("f128", 4, 256, 1, 8), ("f64", 4, 64, 2, 2), ("f128", 5, 64, 1, 8), ("f128", 5, 512, 2, 4), ("f128", 6, 128, 2, 8),
+         ("f128", 6, 32, 1, 4)]
 
 
 @pytest.mark.parametrize("fname,air_id,n,D,blowup", CASES)
@@ -82,7 +99,8 @@ def test_argument_checks(wf, oracle):
         prover.DefaultConstraintEvaluator(air_mod.FibSmall(16, 1), prover.ConstraintCompositionCoefficients(np.zeros(3, np.uint64), np.zeros(3, np.uint64)))
 
 
-@pytest.mark.parametrize("fname,air_id,log_n,D", [("f64", 0, 20, 2), ("f128", 1, 16, 2), ("f128", 1, 20, 1)])
+@pytest.mark.parametrize("fname,air_id,log_n,D", [("f64", 0, 20, 2), ("f128", 1, 16, 2), ("f128", 1, 20, 1), ("f128", 4, 16, 2), ("f128", 6, 14, 1),
+                                                  ("f64", 3, 18, 3), ("f128", 2, 16, 1)])
 def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
     """BASELINE configs[2] shape (examples::rescue, 2^20 rows, blowup 8) and fib_small at 2^20: trace commitment ->
     constraint evaluation -> composition polynomial -> constraint commitment, everything device resident.  Checked:
@@ -123,4 +141,5 @@ def test_full_size_pipeline_properties(wf, oracle, fname, air_id, log_n, D):
     nt = air.num_transition_constraints()
     assert ood_constraint_equation_holds(E, one, g, n, z, H, [tev[k * D:(k + 1) * D] for k in range(nt)],
                                          [fld.unpack(c) for c in cc.transition], [fld.unpack(r) for r in cur],
-                                         [(a.column, a.first_step, a.value) for a in ev.assertions], [fld.unpack(c) for c in cc.boundary])
+                                         [(a.column, a.first_step, a.value) for a in ev.assertions], [fld.unpack(c) for c in cc.boundary],
+                                         num_exemptions=air.num_transition_exemptions())

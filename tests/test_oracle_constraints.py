@@ -32,21 +32,39 @@ def _case(oracle, fname, air, n, D, seed, corrupt=False):
         one = new(1)
         res = fld.unpack(trace[1])[n - 1]
         assertions = [(0, 0, one), (1, 0, one), (1, n - 1, res)]
-    else:
+    elif air == fld.AIR_RESCUE:
         trace = fld.rescue_build_trace([42, 43], n // 16)
         ce_blowup, ncols = 4, 3
         t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
         assertions = [(0, 0, t0[0]), (1, 0, t1[0]), (0, n - 1, t0[n - 1]), (1, n - 1, t1[n - 1])]
+    elif air == fld.AIR_FIB8:                        # fib8/air.rs:67-76
+        trace = fld.fib8_build_trace(n)
+        ce_blowup, ncols = 2, 1
+        assertions = [(0, 0, new(13)), (1, 0, new(21)), (1, n - 1, fld.unpack(trace[1])[n - 1])]
+    elif air == fld.AIR_MULFIB2:                     # mulfib2/air.rs:62-71: degree-2 constraints
+        trace = fld.mulfib2_build_trace(n)
+        ce_blowup, ncols = 2, 1
+        assertions = [(0, 0, new(1)), (1, 0, new(2)), (0, n - 1, fld.unpack(trace[0])[n - 1])]
+    elif air == fld.AIR_MULFIB8:                     # mulfib8/air.rs:84-93
+        trace = fld.mulfib8_build_trace(n)
+        ce_blowup, ncols = 2, 1
+        assertions = [(0, 0, new(1)), (1, 0, new(2)), (6, n - 1, fld.unpack(trace[6])[n - 1])]
+    else:                                            # vdf/regular/air.rs:63-66, vdf/exempt/air.rs: degree 3, one column
+        ex = air == fld.AIR_VDF_EXEMPT
+        trace = fld.vdf_build_trace(1234567, n, exempt=ex)
+        ce_blowup, ncols = 2, 2                      # degree 3: ce_blowup = npo2(3 - 1) = 2 (degree.rs min_blowup_factor)
+        last = n - 2 if ex else n - 1
+        assertions = [(0, 0, 1234567), (0, last, fld.unpack(trace[0])[last])]
     if corrupt:
         trace = trace.copy()
-        trace[1, 5 * W] ^= np.uint64(1)
+        trace[min(1, trace.shape[0] - 1), 5 * W] ^= np.uint64(1)
     lde_blowup = 8
     polys, lde, _, _ = fld.build_trace_commitment(0, trace, lde_blowup, offset)
     width, nt, npc, cyc = fld.AIR_SHAPES[air]
     cc_t, cc_b = _rand_e(fld, nt, D, seed), _rand_e(fld, len(assertions), D, seed + 1)
     out = fld.evaluate_constraints(air, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D,
                                    fld.pack(sum(cc_t, [])), [(c, s, fld.pack([v])) for c, s, v in assertions], fld.pack(sum(cc_b, [])))
-    return dict(fld=fld, offset=offset, new=new, polys=polys, out=out, n=n, D=D, ce_blowup=ce_blowup, ncols=ncols, cc_t=cc_t, cc_b=cc_b,
+    return dict(nex=2 if air == getattr(fld, "AIR_VDF_EXEMPT", -1) else 1, fld=fld, offset=offset, new=new, polys=polys, out=out, n=n, D=D, ce_blowup=ce_blowup, ncols=ncols, cc_t=cc_t, cc_b=cc_b,
                 assertions=assertions, air=air, width=width, nt=nt, npc=npc, cyc=cyc)
 
 
@@ -57,7 +75,9 @@ def _composition_coeffs(c):
 
 
 CASES = [("f64", 0, 16, 1), ("f64", 0, 64, 2), ("f64", 0, 32, 3), ("f62", 0, 16, 2), ("f128", 0, 16, 1),
-         ("f128", 1, 32, 1), ("f128", 1, 64, 2)]
+         ("f128", 1, 32, 1), ("f128", 1, 64, 2),
+         ("f128", 2, 32, 1), ("f64", 2, 16, 2), ("f128", 3, 16, 2), ("f64", 3, 32, 3), ("f62", 3, 16, 1), ("f128", 4, 32, 1), ("f64", 4, 16, 2),
+         ("f128", 5, 32, 1), ("f128", 5, 16, 2), ("f128", 6, 32, 2), ("f128", 6, 64, 1)]
 
 
 @pytest.mark.parametrize("fname,air,n,D", CASES)
@@ -87,10 +107,10 @@ def test_prover_evaluation_matches_verifier_formula(oracle, fname, air, n, D):
     curl = fld.unpack(cur.reshape(-1))
     H = E.horner([fld.unpack(row) for row in co], z)
     assert ood_constraint_equation_holds(E, new(1), g, n, z, H, [tev[k * D:(k + 1) * D] for k in range(c["nt"])], c["cc_t"],
-                                         [curl[k * D:(k + 1) * D] for k in range(c["width"])], c["assertions"], c["cc_b"])
+                                         [curl[k * D:(k + 1) * D] for k in range(c["width"])], c["assertions"], c["cc_b"], num_exemptions=c["nex"])
 
 
-@pytest.mark.parametrize("fname,air,n", [("f64", 0, 32), ("f128", 1, 32)])
+@pytest.mark.parametrize("fname,air,n", [("f64", 0, 32), ("f128", 1, 32), ("f64", 3, 32), ("f128", 4, 16)])
 def test_invalid_trace_breaks_divisibility(oracle, fname, air, n):
     """A trace that violates a transition constraint is not divisible by the divisor: the interpolated composition
     polynomial spills over the degree bound (what the prover's debug degree validation catches)."""

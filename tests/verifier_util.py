@@ -36,7 +36,7 @@ class Ext:
         return r
 
 
-def ood_constraint_equation_holds(E, one, g, n, z, H, transition_evals, cc_transition, ood_cur, assertions, cc_boundary):
+def ood_constraint_equation_holds(E, one, g, n, z, H, transition_evals, cc_transition, ood_cur, assertions, cc_boundary, num_exemptions=1):
     """H(z) == sum_k cc_k C_k(z) / Z_t(z) + sum_groups sum_a cc_a (T_col(z) - value) / (z - g^step), cross-multiplied so no
     extension-field inversion is needed.  All arguments are lists of internal-form ints:
       H: the composition polynomial's value at z;  transition_evals: nt elements (each D ints) = Air::evaluate_transition on
@@ -47,7 +47,9 @@ def ood_constraint_equation_holds(E, one, g, n, z, H, transition_evals, cc_trans
         T = E.add(T, E.mul(cc, ev))
     zn = E.pow(z, n)
     num_t = E.sub(zn, E.lift(one))                                   # x^n - 1
-    den_t = E.sub(z, E.lift(f.exp(g, n - 1)))                        # the single transition exemption x - g^(n-1)
+    den_t = E.sub(z, E.lift(f.exp(g, n - 1)))                        # transition exemptions: x - g^(n-1) [, x - g^(n-2)] (divisor.rs:43-51)
+    for k in range(2, num_exemptions + 1):
+        den_t = E.mul(den_t, E.sub(z, E.lift(f.exp(g, n - k))))
     groups = {}
     for (col, step, val), cc in zip(assertions, cc_boundary):
         ev = E.sub(ood_cur[col], E.lift(val))

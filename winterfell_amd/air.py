@@ -118,3 +118,61 @@ class RescueAir(_BuiltinAir):
         last = self._n - 1
         return [Assertion.single(0, 0, self.seed[0]), Assertion.single(1, 0, self.seed[1]),
                 Assertion.single(0, last, self.result[0]), Assertion.single(1, last, self.result[1])]
+
+
+class Fib8(_BuiltinAir):
+    """examples/src/fibonacci/fib8/air.rs:18-77: two registers, eight Fibonacci terms per step; the trace starts at the 7th
+    and 8th terms (13, 21)."""
+    AIR_ID, TRACE_WIDTH = 2, 2
+
+    def __init__(self, trace_length, result, blowup_factor=8, field=fields.f128):
+        super().__init__(trace_length, [TransitionConstraintDegree(1), TransitionConstraintDegree(1)], 3, blowup_factor)
+        self.result, self.FIELD = result, field
+
+    def get_assertions(self):
+        f = self.FIELD
+        return [Assertion.single(0, 0, f.new(13)), Assertion.single(1, 0, f.new(21)), Assertion.single(1, self._n - 1, self.result)]
+
+
+class MulFib2(_BuiltinAir):
+    """examples/src/fibonacci/mulfib2/air.rs:18-72: multiplicative Fibonacci, two registers, degree-2 constraints."""
+    AIR_ID, TRACE_WIDTH = 3, 2
+
+    def __init__(self, trace_length, result, blowup_factor=8, field=fields.f128):
+        super().__init__(trace_length, [TransitionConstraintDegree(2), TransitionConstraintDegree(2)], 3, blowup_factor)
+        self.result, self.FIELD = result, field
+
+    def get_assertions(self):
+        f = self.FIELD
+        return [Assertion.single(0, 0, f.new(1)), Assertion.single(1, 0, f.new(2)), Assertion.single(0, self._n - 1, self.result)]
+
+
+class MulFib8(_BuiltinAir):
+    """examples/src/fibonacci/mulfib8/air.rs:18-94: multiplicative Fibonacci over eight registers."""
+    AIR_ID, TRACE_WIDTH = 4, 8
+
+    def __init__(self, trace_length, result, blowup_factor=8, field=fields.f128):
+        super().__init__(trace_length, [TransitionConstraintDegree(2) for _ in range(8)], 3, blowup_factor)
+        self.result, self.FIELD = result, field
+
+    def get_assertions(self):
+        f = self.FIELD
+        return [Assertion.single(0, 0, f.new(1)), Assertion.single(1, 0, f.new(2)), Assertion.single(6, self._n - 1, self.result)]
+
+
+class Vdf(_BuiltinAir):
+    """examples/src/vdf/regular/air.rs:29-71 and vdf/exempt/air.rs (exempt=True: two transition exemptions, the result
+    asserted at the second to last step because the last row holds garbage)."""
+    TRACE_WIDTH = 1
+
+    def __init__(self, trace_length, seed, result, blowup_factor=8, exempt=False, field=fields.f128):
+        super().__init__(trace_length, [TransitionConstraintDegree(3)], 2, blowup_factor)
+        self.seed, self.result, self.exempt, self.FIELD = seed, result, exempt, field
+        self.AIR_ID = 6 if exempt else 5
+
+    def num_transition_exemptions(self):
+        return 2 if self.exempt else 1                                             # vdf/exempt/air.rs:47-48
+
+    def get_assertions(self):
+        last = self._n - 2 if self.exempt else self._n - 1
+        return [Assertion.single(0, 0, self.seed), Assertion.single(0, last, self.result)]

@@ -11,14 +11,18 @@
 //   AIRs: FibSmall (examples/src/fibonacci/fib_small/air.rs:41-59), RescueAir (examples/src/rescue/air.rs:88-138,
 //         examples/src/rescue/rescue.rs:60-123; f128 only, constants generated into rescue_f128_constants.h)
 //
-// AIR transition functions are user Rust closures in the reference, so they cannot cross a C ABI generically: the two
-// example AIRs are hand-written device functions selected by `air`.  Everything around them is generic: one lane per
+//         Fib8 / MulFib2 / MulFib8 (examples/src/fibonacci/{fib8,mulfib2,mulfib8}/air.rs), Vdf regular and exempt
+//         (examples/src/vdf/{regular,exempt}/air.rs; the exempt variant has two transition exemptions)
+//
+// AIR transition functions are user Rust closures in the reference, so they cannot cross a C ABI generically: seven of
+// the reference's example AIRs are hand-written device functions selected by `air`.  Everything around them is generic: one lane per
 // constraint-evaluation step reads its frame straight from the device-resident row-major LDE (no D2H copy of the
 // trace), folds the transition evaluations with the composition coefficients, multiplies by the inverse divisor
 // 1 / (x^n - 1) * (x - g^(n-1)), adds the boundary groups divided by (x - g^step), and writes the combined value.
 // The per-step inverses 1 / (x_i - g^step) come from a batch-inversion kernel (16 steps per lane, one field inversion).
 #include <string.h>
 
+#include <type_traits>
 #include <vector>
 
 #include "dft_regs.cuh"
@@ -36,7 +40,7 @@ constexpr int INV_CHUNK = 16;
 
 // ---- AIRs -------------------------------------------------------------------------------------------------------
 struct AirFibSmall {
-    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1;
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
     struct Consts {};
     template <class F>
     static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
@@ -46,8 +50,65 @@ struct AirFibSmall {
     }
 };
 
+struct AirFib8 {      // examples/src/fibonacci/fib8/air.rs:40-65
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    struct Consts {};
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
+                                                      const Consts &, typename F::T *res) {
+        typename F::T a = F::add(cur[0], cur[1]), b = F::add(cur[1], a);      // n0, n1
+#pragma unroll
+        for (int k = 0; k < 3; k++) {                                          // (n2, n3), (n4, n5), (n6, n7)
+            a = F::add(a, b);
+            b = F::add(b, a);
+        }
+        res[0] = F::sub(next[0], a);
+        res[1] = F::sub(next[1], b);
+    }
+};
+
+struct AirMulFib2 {   // examples/src/fibonacci/mulfib2/air.rs:41-60
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    struct Consts {};
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
+                                                      const Consts &, typename F::T *res) {
+        res[0] = F::sub(next[0], F::mul(cur[0], cur[1]));
+        res[1] = F::sub(next[1], F::mul(cur[1], next[0]));
+    }
+};
+
+struct AirMulFib8 {   // examples/src/fibonacci/mulfib8/air.rs:52-82
+    static constexpr int WIDTH = 8, NT = 8, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    struct Consts {};
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
+                                                      const Consts &, typename F::T *res) {
+        res[0] = F::sub(next[0], F::mul(cur[6], cur[7]));
+        res[1] = F::sub(next[1], F::mul(cur[7], next[0]));
+#pragma unroll
+        for (int k = 2; k < 8; k++) res[k] = F::sub(next[k], F::mul(next[k - 2], next[k - 1]));
+    }
+};
+
+// examples/src/vdf/regular/air.rs:49-61 (EX = 1) and vdf/exempt/air.rs (EX = 2: the last TWO steps are exempt)
+template <int EX>
+struct AirVdf {
+    static constexpr int WIDTH = 1, NT = 1, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = EX;   // degree 3: ce_blowup = npo2(3 - 1) = 2 (degree.rs:96-99)
+    struct Consts {
+        f128::u128 forty_two;    // BaseElement::new(42) in the field's internal form (low word for the 64-bit fields)
+    };
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
+                                                      const Consts &c, typename F::T *res) {
+        typedef typename F::T T;
+        const T cube = F::mul(F::mul(next[0], next[0]), next[0]);
+        res[0] = F::sub(cur[0], F::add(cube, (T)c.forty_two));
+    }
+};
+
 struct AirRescue {   // F128 only
-    static constexpr int WIDTH = 4, NT = 4, NP = 9, CYCLE = 16, LOG_CE = 2;
+    static constexpr int WIDTH = 4, NT = 4, NP = 9, CYCLE = 16, LOG_CE = 2, EXEMPT = 1;
     struct Consts {
         f128::u128 mds[16], inv_mds[16];
     };
@@ -147,7 +208,7 @@ struct EvalParams {
     uint32_t x_log_lo;
     const T *ptab;                // periodic table [plen][NP]
     const T *zt;                  // [ce_blowup] inverse transition-divisor numerators
-    T exempt;                     // g^(n-1)
+    T exempt, exempt2;            // g^(n-1), g^(n-2): the steps the transition divisor exempts (divisor.rs:43-51)
     const T *zb;                  // [ngroups][ce]
     const T *cc_t;                // [NT][D]
     uint32_t num_assert, ngroups;
@@ -188,7 +249,8 @@ __global__ __launch_bounds__(256) void constraints_kernel(EvalParams<typename F:
         for (int k = 1; k < AIR::NT; k++) acc[d] = F::add(acc[d], F::mul(p.cc_t[k * D + d], tev[k]));
     }
     const T x = series_at<F>(p.x_lo, p.x_hi, p.x_log_lo, step);
-    const T ze = F::mul(p.zt[step & ((1u << p.log_ce_blowup) - 1)], F::sub(x, p.exempt));
+    T ze = F::mul(p.zt[step & ((1u << p.log_ce_blowup) - 1)], F::sub(x, p.exempt));
+    if (AIR::EXEMPT == 2) ze = F::mul(ze, F::sub(x, p.exempt2));
 #pragma unroll
     for (int d = 0; d < D; d++) acc[d] = F::mul(acc[d], ze);
     for (uint32_t q = 0; q < p.ngroups; q++) {
@@ -236,12 +298,9 @@ static typename HF::T hsub(typename HF::T a, typename HF::T b) {
     return a >= b ? a - b : a + (HostOps<HF>::modulus() - b);
 }
 
-// periodic column values of the AIR (canonical integers), NP columns of CYCLE values
+// periodic column values of the AIR (canonical integers), NP columns of CYCLE values; only the Rescue example has any
 template <class HF, class AIR>
-static void periodic_values(std::vector<std::vector<typename HF::T>> &cols);
-template <> void periodic_values<HostF64, AirFibSmall>(std::vector<std::vector<HostF64::T>> &cols) { cols.clear(); }
-template <> void periodic_values<HostF128, AirFibSmall>(std::vector<std::vector<HostF128::T>> &cols) { cols.clear(); }
-template <> void periodic_values<HostF62, AirFibSmall>(std::vector<std::vector<HostF62::T>> &cols) { cols.clear(); }
+static void periodic_values(std::vector<std::vector<typename HF::T>> &cols) { cols.clear(); }
 template <> void periodic_values<HostF128, AirRescue>(std::vector<std::vector<HostF128::T>> &cols) {
     cols.assign(9, std::vector<HostF128::T>(16));
     for (int i = 0; i < 16; i++) cols[0][i] = i < 14 ? 1 : 0;                 // CYCLE_MASK, examples/src/rescue/air.rs:18-35
@@ -249,13 +308,17 @@ template <> void periodic_values<HostF128, AirRescue>(std::vector<std::vector<Ho
         for (int i = 0; i < 16; i++) cols[1 + j][i] = RESCUE_ARK[i][j];      // get_round_constants, rescue.rs:92-107
 }
 
-template <class AIR>
-static void fill_consts(typename AIR::Consts &c);
-template <> void fill_consts<AirFibSmall>(AirFibSmall::Consts &) {}
-template <> void fill_consts<AirRescue>(AirRescue::Consts &c) {
-    for (int i = 0; i < 16; i++) {
-        c.mds[i] = RESCUE_MDS[i];
-        c.inv_mds[i] = RESCUE_INV_MDS[i];
+template <class HF, class AIR>
+static void fill_consts(typename AIR::Consts &c) {
+    if constexpr (std::is_same<AIR, AirRescue>::value) {
+        for (int i = 0; i < 16; i++) {
+            c.mds[i] = RESCUE_MDS[i];
+            c.inv_mds[i] = RESCUE_INV_MDS[i];
+        }
+    } else if constexpr (std::is_same<AIR, AirVdf<1>>::value || std::is_same<AIR, AirVdf<2>>::value) {
+        c.forty_two = (f128::u128)HF::to_internal(HF::from_u64(42));
+    } else {
+        (void)c;
     }
 }
 
@@ -396,6 +459,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.ptab = d_ptab;
     p.zt = d_zt;
     p.exempt = exempt;
+    p.exempt2 = HF::to_internal(HF::powmod(g_trace, n - 2));
     p.zb = d_zb;
     p.cc_t = d_cct;
     p.num_assert = num_assert;
@@ -406,7 +470,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.cc_b = d_ccb;
     p.out = (T *)d_out;
     typename AIR::Consts consts;
-    fill_consts<AIR>(consts);
+    fill_consts<HF, AIR>(consts);
     wf_prof_begin(ctx, "evaluate_constraints");
     hipLaunchKernelGGL((constraints_kernel<F, AIR, D>), dim3((uint32_t)((ce + 255) / 256)), dim3(256), 0, ctx->stream, p, consts);
     wf_prof_end(ctx);
@@ -446,6 +510,19 @@ extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t
             default: return WF_ERR_UNSUPPORTED;
         }
     }
+#define WF_EVAL_ANY_FIELD(AIR)                                  \
+    switch (field) {                                            \
+        case WF_FIELD_F64: WF_EVAL(HostF64, AIR);               \
+        case WF_FIELD_F128: WF_EVAL(HostF128, AIR);             \
+        case WF_FIELD_F62: WF_EVAL(HostF62, AIR);               \
+        default: return WF_ERR_UNSUPPORTED;                     \
+    }
+    if (air == WF_AIR_FIB8) { WF_EVAL_ANY_FIELD(AirFib8) }
+    if (air == WF_AIR_MULFIB2) { WF_EVAL_ANY_FIELD(AirMulFib2) }
+    if (air == WF_AIR_MULFIB8) { WF_EVAL_ANY_FIELD(AirMulFib8) }
+    if (air == WF_AIR_VDF) { WF_EVAL_ANY_FIELD(AirVdf<1>) }
+    if (air == WF_AIR_VDF_EXEMPT) { WF_EVAL_ANY_FIELD(AirVdf<2>) }
+#undef WF_EVAL_ANY_FIELD
     if (air == WF_AIR_RESCUE) {
         if (field != WF_FIELD_F128) return WF_ERR_UNSUPPORTED;   // the example's constants live in f128 (examples/src/rescue/rescue.rs:8)
         WF_EVAL(HostF128, AirRescue);
