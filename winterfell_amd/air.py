@@ -1,5 +1,5 @@
 """The slice of the reference's `air` crate the GPU constraint evaluator needs: Assertion::single, the AirContext
-arithmetic (ce_blowup_factor, number of composition columns, transition exemptions) and the two example AIRs whose
+arithmetic (ce_blowup_factor, number of composition columns, transition exemptions) and the example AIRs whose
 transition functions are built into the library (include/winterfell_hip.h: WF_AIR_FIB_SMALL, WF_AIR_RESCUE).
 
 Values are python ints in the field's INTERNAL representation (fields.Field.new / as_int)."""
