@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <vector>
 
+#include "batch_inv.cuh"
 #include "dft_regs.cuh"
 #include "tables.cuh"
 #include "wf_internal.h"
@@ -151,34 +152,18 @@ struct AirRescue {   // F128 only
     }
 };
 
-// ---- field inversion by exponentiation (exponent = modulus - 2, passed in as two words) ---------------------------
-template <class F>
-__device__ __forceinline__ typename F::T field_inv(typename F::T a, typename F::T one, uint64_t e_lo, uint64_t e_hi) {
-    typename F::T r = one;
-    bool started = false;
-    for (int bit = 127; bit >= 0; bit--) {
-        const uint64_t w = bit >= 64 ? e_hi : e_lo;
-        const bool set = (w >> (bit & 63)) & 1;
-        if (started) r = F::mul(r, r);
-        if (set) {
-            r = started ? F::mul(r, a) : a;
-            started = true;
-        }
-    }
-    return r;
-}
-
-// zb[q][i] = 1 / (x_i - b_q),  x_i = offset * g_ce^i  (series table),  INV_CHUNK consecutive i per lane
+// zb[q][i] = 1 / (x_i - b_q),  x_i = offset * g_ce^i  (series table),  INV_CHUNK consecutive i per lane, one field inversion per
+// workgroup (batch_inv.cuh)
 template <class F>
 __global__ __launch_bounds__(256) void divisor_inv_kernel(const typename F::T *x_lo, const typename F::T *x_hi, uint32_t x_log_lo,
                                                           uint64_t ce, const typename F::T *b, typename F::T one, uint64_t e_lo,
                                                           uint64_t e_hi, typename F::T *zb) {
     typedef typename F::T T;
+    __shared__ T sA[256], sB[256];
     const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * INV_CHUNK;
-    if (i0 >= ce) return;
     const uint32_t q = blockIdx.y;
     const T bq = b[q];
-    const uint32_t cnt = ce - i0 < INV_CHUNK ? (uint32_t)(ce - i0) : INV_CHUNK;
+    const uint32_t cnt = i0 >= ce ? 0u : (ce - i0 < INV_CHUNK ? (uint32_t)(ce - i0) : (uint32_t)INV_CHUNK);
     T v[INV_CHUNK], pre[INV_CHUNK];
     T acc = one;
 #pragma unroll
@@ -189,7 +174,7 @@ __global__ __launch_bounds__(256) void divisor_inv_kernel(const typename F::T *x
             acc = F::mul(acc, v[k]);
         }
     }
-    acc = field_inv<F>(acc, one, e_lo, e_hi);
+    acc = block_inverse_of_products<F>(acc, one, e_lo, e_hi, sA, sB);
 #pragma unroll
     for (int k = INV_CHUNK - 1; k >= 0; k--) {
         if ((uint32_t)k < cnt) {

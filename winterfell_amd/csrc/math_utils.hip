@@ -6,6 +6,7 @@
 
 #include <vector>
 
+#include "batch_inv.cuh"
 #include "fields.cuh"
 #include "wf_internal.h"
 
@@ -35,31 +36,15 @@ __global__ __launch_bounds__(256) void power_series_kernel(Pow2Table<typename F:
     }
 }
 
-// a^(modulus - 2) by square and multiply
-template <class F>
-__device__ __forceinline__ typename F::T inv_fermat(typename F::T a, typename F::T one, uint64_t e_lo, uint64_t e_hi) {
-    typename F::T r = one;
-    bool started = false;
-    for (int bit = 127; bit >= 0; bit--) {
-        const bool set = ((bit >= 64 ? e_hi : e_lo) >> (bit & 63)) & 1;
-        if (started) r = F::mul(r, r);
-        if (set) {
-            r = started ? F::mul(r, a) : a;
-            started = true;
-        }
-    }
-    return r;
-}
-
-// serial_batch_inversion (utils/mod.rs:194-215) over runs of RUN elements per lane: prefix products skipping zeros, one
-// inversion, walk back; zero inputs give zero outputs
+// serial_batch_inversion (utils/mod.rs:194-215) over runs of RUN elements per lane: prefix products skipping zeros, one field
+// inversion per WORKGROUP (batch_inv.cuh), walk back; zero inputs give zero outputs
 template <class F>
 __global__ __launch_bounds__(256) void batch_inversion_kernel(const typename F::T *in, uint64_t n, typename F::T one, uint64_t e_lo,
                                                               uint64_t e_hi, typename F::T *out) {
     typedef typename F::T T;
+    __shared__ T sA[256], sB[256];
     const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * RUN;
-    if (i0 >= n) return;
-    const uint32_t cnt = n - i0 < RUN ? (uint32_t)(n - i0) : RUN;
+    const uint32_t cnt = i0 >= n ? 0u : (n - i0 < RUN ? (uint32_t)(n - i0) : (uint32_t)RUN);
     T v[RUN], pre[RUN];
     T last = one;
 #pragma unroll
@@ -70,7 +55,7 @@ __global__ __launch_bounds__(256) void batch_inversion_kernel(const typename F::
             if (!F::is_zero(v[k])) last = F::mul(last, v[k]);
         }
     }
-    last = inv_fermat<F>(last, one, e_lo, e_hi);
+    last = block_inverse_of_products<F>(last, one, e_lo, e_hi, sA, sB);
 #pragma unroll
     for (int k = RUN - 1; k >= 0; k--) {
         if ((uint32_t)k < cnt) {
