@@ -108,6 +108,34 @@ int main() {
         EXPECT(threw, "non power-of-two length is rejected (fft/mod.rs:90-93)");
     }
 
+    // ---- wf_malloc / wf_free: the stream-ordered pool hands a freed block to the next request of that size class, trims on demand ----
+    {
+        void *a = nullptr, *b = nullptr, *c = nullptr;
+        wf::check(wf_malloc(ctx.handle(), 3u << 20, &a), "wf_malloc");
+        wf::check(wf_free(ctx.handle(), a), "wf_free");
+        wf::check(wf_malloc(ctx.handle(), (3u << 20) - 4096, &b), "wf_malloc");          // same 2 MiB size class: the cached block
+        wf::check(wf_malloc(ctx.handle(), 3u << 20, &c), "wf_malloc");                   // pool empty again: a fresh block
+        EXPECT(a == b && c != b, "freed block is reused for the next request of its size class");
+        wf::check(wf_free(ctx.handle(), b), "wf_free");
+        wf::check(wf_free(ctx.handle(), c), "wf_free");
+        wf::check(wf_ctx_trim(ctx.handle()), "wf_ctx_trim");
+        void *d = nullptr;
+        wf::check(wf_malloc(ctx.handle(), 100, &d), "wf_malloc");
+        wf::check(wf_free(ctx.handle(), d), "wf_free");
+        wf::check(wf_free(ctx.handle(), nullptr), "wf_free(nullptr)");
+        // a freed buffer may be reused while work that read it is still queued: results must not change
+        std::vector<uint64_t> p = rand_vec(1 << 12), want = p;
+        or_f64t_evaluate_poly(want.data(), 1 << 12, 1);
+        bool ok = true;
+        for (int it = 0; it < 8; it++) {
+            wf::DeviceBuffer x(ctx, p);
+            wf::fft::evaluate_poly(x, F, 1 << 12);
+            wf::DeviceBuffer y = x.clone();          // y's block = whatever the previous iteration freed
+            ok = ok && y.to_host<uint64_t>() == want;
+        }
+        EXPECT(ok, "buffers recycled without synchronisation keep their contents (stream order)");
+    }
+
     // ---- build_trace_commitment + MerkleTree (Blake3_256 and Rp64_256, partitions) ---------------------------------------------
     for (int hasher = 0; hasher < 2; hasher++) {
         const uint64_t n = 1 << 8, c = 12, blowup = 8, N = n * blowup, parts = hasher == 0 ? 4 : 1;

@@ -408,3 +408,23 @@ def test_hasher_hash_bytes(wf, oracle):
     f62 = fields.f62
     verbatim = [int.from_bytes(m70[7 * k:7 * k + 7], "little") for k in range(10)]
     assert np.array_equal(crypto.Rp62_248.hash(m70), crypto.Rp62_248.hash_elements(f62.pack([f62.new(v) for v in verbatim])))
+
+
+@pytest.mark.parametrize("hname,hid", [("Blake3_256", 0), ("Rp64_256", 1), ("Sha3_256", 2), ("RpJive64_256", 3), ("Blake3_192", 5)])
+@pytest.mark.parametrize("rows,cols,width,parts,rate,D", [(1000, 24, 24, 3, 1, 1), (37, 20, 24, 2, 8, 2), (65, 9, 16, 1, 1, 1), (4097, 40, 40, 16, 1, 1),
+                                                           (1, 130, 136, 1, 1, 1), (129, 17, 17, 1, 1, 1)])
+def test_hash_rows_ragged_shapes_every_kernel_path(wf, oracle, hname, hid, rows, cols, width, parts, rate, D):
+    """wf_hash_rows on row counts that are not multiples of the 64-row wavefront / 16-lane group, padded row widths, partitions
+    with a short last chunk and a hash_rate floor — the wave-cooperative wide-row kernels (BLAKE3 / SHA3), the lane-cooperative
+    Rescue kernels (few rows) and the per-lane kernels all against the oracle's hash_rows (row_matrix.rs:184-228)."""
+    ctx, crypto, prover, fields = wf
+    hasher = getattr(crypto, hname)
+    data = np.zeros((rows, width), dtype=np.uint64)
+    data[:, :cols] = oracle.f64_from_int(rand_field(rows + cols, rows * cols)).reshape(rows, cols)
+    data[:, cols:] = np.uint64(0xDEAD)                     # padding must never be hashed
+    if cols % D:
+        pytest.skip("columns must hold whole extension elements")
+    m = prover.RowMatrix(ctx.to_device(data), width, cols, D, ctx, fields.f64)
+    got = ctx.to_host(m.hash_rows(hasher, prover.PartitionOptions(parts, rate)))
+    want = oracle.hash_rows(hid, data, cols, D=D, num_partitions=parts, hash_rate=rate)
+    assert np.array_equal(got, want)
