@@ -113,6 +113,23 @@ def main():
     # Every rank owns 4 of the 4*N f64 columns of a 2^20-row trace; this is the one place the path has an exchange step.
     sharded = None
     if world > 1 and not args.no_extra:
+        # Merkle leaves/s over all ranks (north_star: reported at 1/2/4/8 GPUs): one independent 2^23-leaf BLAKE3 tree per rank,
+        # no data-path collective, barrier + max over ranks like the headline
+        merkle_total = None
+        try:
+            lv = ctx.to_device(np.random.default_rng(3 + rank).integers(0, 256, (1 << 23, 32), dtype=np.uint8))
+            crypto.MerkleTree.new(crypto.Blake3_256, lv)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(5):
+                crypto.MerkleTree.new(crypto.Blake3_256, lv)
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / 5], dtype=torch.float64, device="cuda")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            merkle_total = world * (1 << 23) / float(tt.item())
+            del lv
+        except Exception as e:
+            merkle_total = repr(e)[:200]
         try:
             from winterfell_amd import parallel
             tn, tb = 1 << 20, 8
@@ -133,6 +150,11 @@ def main():
             sharded = {"sharded_lde_commit_ms_2^20x%d_b8_blake3" % (4 * world): float(tt.item())}
         except Exception as e:  # never let the optional leg break the headline measurement
             sharded = {"sharded_lde_commit_error": repr(e)[:200]}
+        if isinstance(merkle_total, float):
+            sharded["merkle_blake3_leaves_per_s_2^23_all_ranks"] = merkle_total
+            sharded["merkle_blake3_hbm_roofline_frac_per_gpu"] = 64.0 * merkle_total / world / (HBM_PEAK_GBS * 1e9)
+        elif merkle_total is not None:
+            sharded["merkle_all_ranks_error"] = merkle_total
         # row-strided sharding of ONE 2^20 x 4 trace (replicated input): bit-identical to the default single-device
         # commitment; rank k evaluates and hashes the LDE rows r = k (mod N), leaves cross xGMI (equal-size all-to-all)
         try:
@@ -290,6 +312,7 @@ def main():
             lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
             ms = timed(lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))
             ex["merkle_blake3_leaves_per_s_2^23"] = (1 << 23) / (ms * 1e-3)
+            ex["merkle_blake3_hbm_roofline_frac"] = 64.0 * (1 << 23) / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9)   # 64 B per leaf
             del lv
             # FRI commit phase (configs[4] shape): 2^24 LDE domain, f64 quadratic extension, folding 4, rem-deg 31
             from winterfell_amd import fri as wfri
