@@ -28,6 +28,10 @@ struct Digest {
     uint32_t w[8];
 };
 
+#ifndef WF_B3_STAGE_LEVELS
+#define WF_B3_STAGE_LEVELS 10
+#endif
+
 // ---- per-hasher primitives on 32-byte digests ----------------------------------------------------------------
 struct HBlake3 {
     static constexpr bool WIDE = true;               // rows of >= 64 bytes: wave-cooperative block loads (hash_rows_wide_kernel)
@@ -61,7 +65,7 @@ struct HBlake3 {
     }
     static constexpr bool COOP = false;
     // levels reduced per Merkle launch: BLAKE3 merges are cheap, so a workgroup walks 10 levels through LDS
-    static constexpr uint32_t STAGE_LEVELS = 10;
+    static constexpr uint32_t STAGE_LEVELS = WF_B3_STAGE_LEVELS;
     static const char *row_name() { return "hash_rows_blake3"; }
     static const char *merkle_name() { return "merkle_stage_blake3"; }
     static const char *grind_name() { return "grind_blake3"; }
@@ -112,7 +116,7 @@ struct HBlake3_192 {
         out[6] = out[7] = 0;
     }
     static constexpr bool COOP = false;
-    static constexpr uint32_t STAGE_LEVELS = 10;
+    static constexpr uint32_t STAGE_LEVELS = WF_B3_STAGE_LEVELS;
     static const char *row_name() { return "hash_rows_blake3_192"; }
     static const char *merkle_name() { return "merkle_stage_blake3_192"; }
     static const char *grind_name() { return "grind_blake3_192"; }
