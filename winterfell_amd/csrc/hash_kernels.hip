@@ -523,6 +523,84 @@ __global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void 
     }
 }
 
+// The same for 4096 inputs per workgroup, 12 levels per launch.  In merkle_stage_kernel every level below 64 merges still costs
+// one wavefront step (levels 4..9: six steps for 63 merges out of 21 per 1024 inputs); here a workgroup takes four 1024-input
+// chunks through levels 0..3 one after the other, parks their 4 x 64 digests in LDS and runs the thin levels ONCE for all four:
+// 69 wavefront steps for 4095 merges (93 % of lanes busy instead of 76 %), and a 2^23-leaf tree is two launches.
+template <class H>
+__global__ __launch_bounds__(256) void merkle_stage4k_kernel(const void *in, void *nodes, uint64_t count) {
+    __shared__ uint4 bufA[512 * 2];
+    __shared__ uint4 bufB[256 * 2];
+    __shared__ uint4 top[256 * 2];
+    const uint64_t wg = blockIdx.x;
+    const uint32_t tid = threadIdx.x;
+    auto from_lds = [&](const uint4 *src, uint32_t i, uint32_t (&m)[16]) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const uint4 v = src[4 * i + q];
+            m[4 * q] = v.x;
+            m[4 * q + 1] = v.y;
+            m[4 * q + 2] = v.z;
+            m[4 * q + 3] = v.w;
+        }
+    };
+    auto to_lds = [&](uint4 *dst, uint32_t i, const uint32_t (&d)[8]) {
+        dst[2 * i] = make_uint4(d[0], d[1], d[2], d[3]);
+        dst[2 * i + 1] = make_uint4(d[4], d[5], d[6], d[7]);
+    };
+    // level d (0-based) of this launch: count >> (d + 1) nodes at heap index (count >> (d + 1)) + position
+    for (uint32_t q = 0; q < 4; q++) {
+        const uint64_t base = wg * 4096 + q * 1024;             // first input of the chunk
+        for (uint32_t i = tid; i < 512; i += 256) {             // level 0: from global
+            uint32_t m[16], d[8];
+            load_pair(in, (base >> 1) + i, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> 1) + (base >> 1) + i, d);
+            to_lds(bufA, i, d);
+        }
+        __syncthreads();
+        {                                                       // level 1: 256 merges
+            uint32_t m[16], d[8];
+            from_lds(bufA, tid, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> 2) + (base >> 2) + tid, d);
+            to_lds(bufB, tid, d);
+        }
+        __syncthreads();
+        if (tid < 128) {                                        // level 2
+            uint32_t m[16], d[8];
+            from_lds(bufB, tid, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> 3) + (base >> 3) + tid, d);
+            to_lds(bufA, tid, d);
+        }
+        __syncthreads();
+        if (tid < 64) {                                         // level 3 -> the chunk's 64 digests
+            uint32_t m[16], d[8];
+            from_lds(bufA, tid, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> 4) + (base >> 4) + tid, d);
+            to_lds(top, q * 64 + tid, d);
+        }
+        __syncthreads();
+    }
+    uint4 *src = top, *dst = bufA;
+    for (uint32_t lvl = 4; lvl < 12; lvl++) {                   // 256 -> 1
+        const uint32_t cnt = 4096u >> (lvl + 1);
+        if (tid < cnt) {
+            uint32_t m[16], d[8];
+            from_lds(src, tid, m);
+            H::merge(m, d);
+            store_digest(nodes, (count >> (lvl + 1)) + ((wg * 4096) >> (lvl + 1)) + tid, d);
+            to_lds(dst, tid, d);
+        }
+        __syncthreads();
+        uint4 *t = src;
+        src = dst;
+        dst = (t == top) ? bufB : t;
+    }
+}
+
 __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint32_t take_bytes, const uint64_t *pos,
                                    uint32_t count, uint8_t *out) {
     const uint32_t words = take_bytes / 8;
@@ -782,6 +860,17 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
             wf_prof_end(ctx);
             WF_HIP(hipGetLastError());
             count = half;
+            in = (const uint8_t *)nodes + count * 32;
+            continue;
+        }
+        if (H::STAGE_LEVELS >= 10 && count >= (1u << 20)) {      // 12 levels per launch, 4096 inputs per workgroup: only when that still fills the chip (>= 256 workgroups)
+            const uint64_t wgs4 = count >> 12;
+            if (wgs4 > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            wf_prof_begin(ctx, H::merkle_name());
+            hipLaunchKernelGGL(merkle_stage4k_kernel<H>, dim3((uint32_t)wgs4), dim3(256), 0, ctx->stream, (const void *)in, nodes, count);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            count = wgs4;
             in = (const uint8_t *)nodes + count * 32;
             continue;
         }
