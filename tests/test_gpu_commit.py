@@ -94,13 +94,16 @@ def test_merkle_reference_fixtures(wf, oracle, golden):
     assert [len(x) for x in bp.nodes] == [0, 0, 0, 0]
 
 
-@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 10, 11, 14, 17])
+@pytest.mark.parametrize("log_n", [1, 2, 5, 9, 10, 11, 14, 17, 20, 21, 22])      # >= 2^20: the 4096-input stage kernel
 def test_merkle_vs_oracle(wf, oracle, log_n):
     ctx, crypto, _, _ = wf
     n = 1 << log_n
     rng = np.random.default_rng(log_n)
     lv = rng.integers(0, 256, (n, 32), dtype=np.uint8)
     assert np.array_equal(crypto.MerkleTree.new(crypto.Blake3_256, lv).nodes, oracle.merkle_build(0, lv, par=True)), log_n
+    if log_n >= 20:
+        lv[:, 24:] = 0
+        assert np.array_equal(crypto.MerkleTree.new(crypto.Blake3_192, lv).nodes, oracle.merkle_build(5, lv, par=True)), log_n
     if log_n <= 14:
         lv = oracle.f64_from_int(rand_field(log_n, n * 4)).view(np.uint8).reshape(n, 32)
         assert np.array_equal(crypto.MerkleTree.new(crypto.Rp64_256, lv).nodes, oracle.merkle_build(1, lv, par=True)), log_n
