@@ -60,6 +60,7 @@ struct PassParams {
     uint32_t post_log_lo;
     uint32_t has_post_const;
     T post_const;
+    const T *tw_tab;          // non-last pass: inter-pass twiddles T[k'][rem] when the table is small (else nullptr: progression)
     uint32_t scale_in_w256;   // last pass of an inverse transform: w256 already carries the 1/n (applied for k_a = 0 too)
     // row-major output mode of the last pass (NttJob::rowmajor)
     uint32_t rowmajor, rm_log_b, rm_log_i, rm_base_cols;
@@ -262,6 +263,17 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
         constexpr int LOG_CNT = decltype(log_cnt_tag)::value;
         constexpr int CNT = 1 << LOG_CNT;
         const uint32_t r32 = (uint32_t)rem;
+        if (p.tw_tab != nullptr) {
+            // small strides: the pass's 2^(LOG_R + log_s) twiddles sit in one L2-resident table, rows of 2^log_s consecutive
+            // `rem` (a tile's 16 columns = one 128-byte run): 16 coalesced loads replace the 15-multiplication chain
+#pragma unroll
+            for (int ip = 0; ip < CNT; ip++) {
+                const int i = brev(ip, LOG_CNT);
+                const uint32_t kp = k0 + step_k * (uint32_t)ip;
+                dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(vals[i], p.tw_tab[((uint64_t)kp << log_s) + r32]);
+            }
+            return;
+        }
         T cur = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (k0 * r32) << log_mult);
         const T stp = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (step_k * r32) << log_mult);
 #pragma unroll
@@ -339,6 +351,44 @@ static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, u
         rem -= r;
     }
     for (uint32_t q = npass; q < 6; q++) log_r[q] = 0;
+}
+
+#ifndef NTT_TW_TABLE_MAX_LOG
+#define NTT_TW_TABLE_MAX_LOG 17   // largest inter-pass twiddle table kept (entries): 1 MiB of f64, L2 resident
+#endif
+
+namespace {
+template <class F>
+__global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename F::T *w_lo, const typename F::T *w_hi, uint32_t w_log_lo,
+                                                                 uint32_t log_s, uint32_t log_mult, uint32_t log_total, typename F::T *out) {
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >> log_total) return;
+    const uint32_t kp = idx >> log_s, rem = idx & ((1u << log_s) - 1);
+    out[idx] = series_at32<F>(w_lo, w_hi, w_log_lo, (kp * rem) << log_mult);
+}
+}  // namespace
+
+template <class HF>
+static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uint32_t r, uint32_t log_s, uint32_t log_mult, const void **out) {
+    typedef typename HF::Dev F;
+    typedef typename F::T T;
+    *out = nullptr;
+    const uint32_t log_total = r + log_s;
+    if (NTT_TW_TABLE_MAX_LOG == 0 || log_total > NTT_TW_TABLE_MAX_LOG) return WF_OK;
+    auto key = std::make_tuple((int)F::ID, L, r, log_s, log_mult);
+    auto it = ctx->pass_twiddles.find(key);
+    if (it == ctx->pass_twiddles.end()) {
+        void *d;
+        WF_HIP(hipMalloc(&d, sizeof(T) << log_total));
+        ctx->owned.push_back(d);
+        const uint32_t total = 1u << log_total;
+        hipLaunchKernelGGL(pass_twiddle_table_kernel<F>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, (const T *)om.d_lo, (const T *)om.d_hi,
+                           om.log_lo, log_s, log_mult, log_total, (T *)d);
+        WF_HIP(hipGetLastError());
+        it = ctx->pass_twiddles.emplace(key, d).first;
+    }
+    *out = it->second;
+    return WF_OK;
 }
 
 template <class HF>
@@ -428,6 +478,14 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
             p.w256 = (const T *)ws;
             p.scale_in_w256 = 1;
+        }
+        p.tw_tab = nullptr;
+        if (!last) {
+            uint32_t log_s = L;
+            for (uint32_t qq = 0; qq <= q; qq++) log_s -= p.log_r[qq];
+            const void *tab;
+            WF_TRY(get_pass_twiddles<HF>(ctx, om, L, r, log_s, L - log_s - r, &tab));
+            p.tw_tab = (const T *)tab;
         }
         const uint32_t Tc = 256u >> log_b_for(r);
         uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;

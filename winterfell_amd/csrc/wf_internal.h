@@ -49,6 +49,9 @@ struct wf_ctx {
     std::map<int, void *> w256, w16;
     // omega_256^e * c for a constant c (the 1/n of an inverse transform folded into the last pass's twiddles)
     std::map<std::tuple<int, uint64_t, uint64_t>, void *> w256_scaled;
+    // inter-pass twiddle tables T[k'][rem] = omega_n^((k' * rem) << log_mult) of the passes whose table is small enough to live in L2;
+    // key (field, log_n, log_r of the pass, log_s, log_mult)
+    std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, void *> pass_twiddles;
     // LDE pre-scale tables: key (field, offset (128 bit), log_n, log_blowup) -> contiguous [u][lo] / [u][hi]
     struct LdeTables {
         void *d_lo = nullptr, *d_hi = nullptr;
