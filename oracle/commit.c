@@ -219,6 +219,7 @@ void or_evaluate_polys_over(const uint64_t *polys, uint64_t c, uint64_t n, unsig
 /* PartitionOptions::partition_size / num_partitions — air/src/options.rs:428-444 (in columns of E) */
 uint64_t or_partition_size(uint64_t num_partitions, uint64_t hash_rate, unsigned D, uint64_t num_columns) {
     if (num_partitions == 1) return num_columns;
+    hash_rate &= 0xff; /* PartitionOptions::new stores `hash_rate as u8` (options.rs:414-418): the permitted 256 wraps to 0 */
     uint64_t min_ps = hash_rate / D;
     uint64_t ps = (num_columns + num_partitions - 1) / num_partitions;
     return ps > min_ps ? ps : min_ps;

@@ -149,6 +149,9 @@ def test_fib_trace_lde_fixture(wf, oracle, golden):
     ("Blake3_256", 150, 6, 2, 1),    # > 1 BLAKE3 chunk per row
     ("Rp64_256", 3, 13, 8, 1),
     ("Blake3_256", 9, 16, 8, 1),     # 2 column groups, 3-pass NTT on the LDE domain
+    ("Blake3_256", 3, 8, 8, 4),      # partition size 4 (hash_rate floor) ABOVE the 3 columns: merge_many over one digest
+    ("Rp64_256", 3, 7, 8, 4),
+    ("Blake3_256", 4, 8, 8, 2),      # partition size == column count: the plain row hash (row_matrix.rs:193)
 ])
 def test_build_trace_commitment_vs_oracle(wf, oracle, hname, c, log_n, blowup, parts):
     ctx, crypto, prover, fields = wf
@@ -415,7 +418,13 @@ def test_hasher_hash_bytes(wf, oracle):
 
 @pytest.mark.parametrize("hname,hid", [("Blake3_256", 0), ("Rp64_256", 1), ("Sha3_256", 2), ("RpJive64_256", 3), ("Blake3_192", 5)])
 @pytest.mark.parametrize("rows,cols,width,parts,rate,D", [(1000, 24, 24, 3, 1, 1), (37, 20, 24, 2, 8, 2), (65, 9, 16, 1, 1, 1), (4097, 40, 40, 16, 1, 1),
-                                                           (1, 130, 136, 1, 1, 1), (129, 17, 17, 1, 1, 1)])
+                                                           (1, 130, 136, 1, 1, 1), (129, 17, 17, 1, 1, 1),
+                                                           # partition size ABOVE the column count (hash_rate floor): still
+                                                           # merge_many over the single digest (row_matrix.rs:193; the case
+                                                           # PartitionOptions::new(4, 8) with 7 columns of the reference's tests)
+                                                           (300, 7, 8, 4, 8, 1), (70, 3, 8, 4, 8, 1), (33, 6, 8, 2, 16, 2),
+                                                           # hash_rate 256 is stored `as u8` = 0 by the reference
+                                                           (40, 24, 24, 4, 256, 1)])
 def test_hash_rows_ragged_shapes_every_kernel_path(wf, oracle, hname, hid, rows, cols, width, parts, rate, D):
     """wf_hash_rows on row counts that are not multiples of the 64-row wavefront / 16-lane group, padded row widths, partitions
     with a short last chunk and a hash_rate floor — the wave-cooperative wide-row kernels (BLAKE3 / SHA3), the lane-cooperative

@@ -1,8 +1,10 @@
 """CPU tests of the host-side mirror: representation helpers, PartitionOptions, Merkle openings (index logic)."""
+import os
+
 import numpy as np
 import pytest
 
-from conftest import P, splitmix64
+from conftest import P, ROOT, splitmix64
 
 
 def test_field_representation_helpers(oracle):
@@ -193,3 +195,16 @@ def test_vector_commitment_names(oracle):
     items, mp = tree.open_many([2, 3, 9])
     assert MerkleTree.get_multiproof_domain_len(mp) == 16
     assert MerkleTree.verify_many(h, tree.commitment(), [2, 3, 9], items, mp) is None
+
+
+def test_limb_arithmetic_of_the_f64_ntt_passes_on_the_host(tmp_path):
+    """winterfell_amd/csrc/l24.cuh (the carry-free 24-bit-limb DFTs of the f64 NTT passes, their bias vector, the
+    multiply-accumulate exit and its fold) compiled with g++ and checked against big-integer DFTs over p — the planner's
+    sign / rotation / known-zero bookkeeping and every carry path of the fold, without a GPU.  (On the GPU the same header
+    is covered bit for bit by tests/test_gpu_fft.py; the device-only inline-assembly fold only exists there.)"""
+    import subprocess
+    exe = str(tmp_path / "l24_host_test")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", os.path.join(ROOT, "tests", "cpp", "l24_host_test.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("ok")

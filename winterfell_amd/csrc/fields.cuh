@@ -18,6 +18,11 @@ struct F64 {
 #endif
     static constexpr uint32_t MAX_LOG_RADIX = NTT_F64_MAX_LOG_RADIX;
     static constexpr bool SHIFT_TWIDDLES = true;
+#ifndef NTT_F64_NO_L24
+    static constexpr bool USE_L24 = true;     // NTT passes run their register DFTs on 24-bit limbs (l24.cuh)
+#else
+    static constexpr bool USE_L24 = false;
+#endif
     static __device__ __forceinline__ T add(T a, T b) { return gl::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return gl::sub(a, b); }
     static __device__ __forceinline__ T mul(T a, T b) { return gl::mul(a, b); }
@@ -49,6 +54,7 @@ struct F128 {
 #endif
     static constexpr uint32_t MAX_LOG_RADIX = NTT_F128_MAX_LOG_RADIX;
     static constexpr bool SHIFT_TWIDDLES = false;
+    static constexpr bool USE_L24 = false;
     static __device__ __forceinline__ T add(T a, T b) { return f128::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return f128::sub(a, b); }
     static __device__ __forceinline__ T mul(T a, T b) { return f128::mul(a, b); }
@@ -92,6 +98,7 @@ struct F62 {
     static constexpr int MAX_EXT = 3;
     static constexpr uint32_t MAX_LOG_RADIX = 8;
     static constexpr bool SHIFT_TWIDDLES = false;
+    static constexpr bool USE_L24 = false;
     static __device__ __forceinline__ T add(T a, T b) { return f62::add(a, b); }
     static __device__ __forceinline__ T sub(T a, T b) { return f62::sub(a, b); }
     static __device__ __forceinline__ T mul(T a, T b) { return f62::mul(a, b); }

@@ -984,7 +984,8 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
     if (field != WF_FIELD_F64 && (hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256)) return WF_ERR_UNSUPPORTED;   // Rescue over f64 only
     if (field != WF_FIELD_F62 && hash == WF_HASH_RP62_248) return WF_ERR_UNSUPPORTED;                                       // Rescue over f62 only
     if (elems_per_row > row_width || elems_per_row % D) return WF_ERR_INVALID_ARG;
-    if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
+    if (num_partitions < 1 || num_partitions > 16 || hash_rate < 1 || hash_rate > 256) return WF_ERR_INVALID_ARG;
+    hash_rate &= 0xffu;   // PartitionOptions::new stores `hash_rate as u8` (air/src/options.rs:414-418): the permitted 256 wraps to 0
     // f64 is not IS_CANONICAL: hash the canonical LE bytes; f128 is: hash the raw element bytes (blake/mod.rs:52-65).
     // Rows are addressed in 64-bit words: an f128 element is two words.
     const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : (field == WF_FIELD_F62 ? MODE_F62_CANON : MODE_RAW);
@@ -1001,7 +1002,9 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
         ps = (num_cols + num_partitions - 1) / num_partitions;
         if (ps < min_ps) ps = min_ps;
     }
-    if (ps >= num_cols) {
+    // row_matrix.rs:193: the single-hash path is taken only when partition_size == num_cols; a partition size ABOVE the
+    // column count (the hash_rate floor with num_partitions > 1) still goes through merge_many over its one digest
+    if (ps == num_cols) {
         return with_hasher(hash, [&](auto h) {
             return launch_hash_rows<decltype(h)>(ctx, rows, num_rows, row_width, elems_per_row, elems_per_row, 1, mode, d_leaves);
         });
@@ -1192,18 +1195,18 @@ extern "C" int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint3
                                          int skip_interpolate, void *d_lde, void *d_leaves, void *d_nodes, void *h_root) {
     if (!ctx || !d_trace || !d_lde || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
-    // extend_execution_trace
+    if (ext_degree == 0 || num_cols == 0 || num_partitions < 1 || num_partitions > 16 || hash_rate < 1 || hash_rate > 256) return WF_ERR_INVALID_ARG;
+    // extend_execution_trace (in place: every argument is validated before the trace is touched)
     if (!skip_interpolate) WF_TRY(wf_interpolate_columns(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n));
-    if (ext_degree == 0 || num_partitions < 1 || num_partitions > 16 || hash_rate < 1) return WF_ERR_INVALID_ARG;
     // (for narrow traces committed with a byte hasher and no partitions the LDE transpose also produces the row hashes)
     const uint64_t N = 1ull << (log_n + log_blowup);
     const uint64_t rw = wf_row_width(num_cols, ext_degree);
     bool one_partition = num_partitions == 1;
     if (!one_partition) {   // PartitionOptions::partition_size (air/src/options.rs:428-437): one partition if it covers all columns
-        const uint32_t min_ps = hash_rate / ext_degree;
+        const uint32_t min_ps = (hash_rate & 0xffu) / ext_degree;
         uint32_t ps = (num_cols + num_partitions - 1) / num_partitions;
         if (ps < min_ps) ps = min_ps;
-        one_partition = ps >= num_cols;
+        one_partition = ps == num_cols;   // row_matrix.rs:193 (ps > num_cols keeps the merge_many step)
     }
     int fused = 0;
     WF_TRY(wf_evaluate_polys_over_fused(ctx, field, ext_degree, d_trace, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde,

@@ -30,6 +30,7 @@
 #include <type_traits>
 
 #include "dft_regs.cuh"
+#include "l24.cuh"
 #include "tables.cuh"
 #include "wf_internal.h"
 
@@ -89,8 +90,11 @@ __device__ __forceinline__ void divmod_uniform(uint32_t x, uint32_t d, uint32_t 
     }
 }
 
-template <class F, int LOG_A, int LOG_B, bool LAST>
+// TWTAB (non-last passes): the inter-pass twiddles come from the pass's L2-resident table (p.tw_tab) instead of the per-lane
+// progression; a compile-time switch so that neither variant carries the other's registers
+template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typename F::T> p) {
+    static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
     typedef typename F::T T;
     constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
     constexpr int TC = 256 / B;         // tile columns
@@ -202,6 +206,39 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
 #pragma unroll
             for (int a = 0; a < A; a++) x[a] = F::zero();
         }
+        if constexpr (F::USE_L24) {
+            // f64: the DFT runs on four 24-bit limbs per element (l24.cuh); leaving that representation IS the intra-pass
+            // twiddle multiplication: p.w256 holds rows of four words omega_256^e T^k mod p (plain integers; the data stay
+            // Montgomery residues because the transform is linear), eight multiply-adds + a fold per element.  The LDS
+            // exchange carries 64-bit words that need not be below p ("lazy"): step 2 splits them into limbs again.
+            typedef l24::Dft<LOG_A> DA;
+            int32_t v[DA::NV];
+#pragma unroll
+            for (int a = 0; a < A; a++) DA::load(v, a, x[a]);
+#ifndef NTT_EXPERIMENT_NO_DFT     // timing experiments only (tools/build_variant.sh): results are wrong without the butterflies
+            DA::run(v);
+#endif
+#pragma unroll
+            for (int i = 0; i < A; i++) {
+                const int ka = brev(i, LOG_A);
+                uint32_t y[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) y[q] = DA::limb(v, i, q);
+                if constexpr (B > 1) {
+                    T val;
+                    if (ka != 0 || (LAST && p.scale_in_w256)) {
+                        const T *w = p.w256 + 4 * ((uint32_t)(ka * b1) << (8 - LOG_R));
+                        val = l24::fold_lazy(l24::mul4(y, w[0], w[1], w[2], w[3]));
+                    } else {
+                        val = l24::fold_lazy(l24::mul4_one(y));
+                    }
+                    if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
+                    else lds[idx_l(ka, t1, b1)] = val;
+                } else {
+                    x[i] = l24::fold(l24::mul4_one(y));
+                }
+            }
+        } else {
         dft_dif<F, LOG_A>(x, p.w16);
         if (B > 1) {
             // intra-pass twiddle omega_R^(k_a * b) = omega_256^((k_a * b) << (8 - LOG_R)), then LDS exchange
@@ -213,6 +250,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
                 else lds[idx_l(ka, t1, b1)] = val;
             }
+        }
         }
     }
 
@@ -259,18 +297,19 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     // omega^((k0 + STEP i) * rem * mult) = base * step^i, so two table look-ups (base, step) and a multiplication chain
     // replace a two-level look-up per output: 2 + (CNT - 1) + CNT multiplications instead of 2 (CNT - 1), but 4 loads
     // instead of 2 CNT and none of the per-output index arithmetic.
-    auto emit_progression = [&](auto &vals, uint32_t k0, uint32_t step_k, auto log_cnt_tag) {
+    // `val(i)` yields the value in register i (for f64 it leaves the limb representation on demand, one element at a time)
+    auto emit_progression = [&](auto &&val, uint32_t k0, uint32_t step_k, auto log_cnt_tag) {
         constexpr int LOG_CNT = decltype(log_cnt_tag)::value;
         constexpr int CNT = 1 << LOG_CNT;
         const uint32_t r32 = (uint32_t)rem;
-        if (p.tw_tab != nullptr) {
+        if constexpr (TWTAB) {
             // small strides: the pass's 2^(LOG_R + log_s) twiddles sit in one L2-resident table, rows of 2^log_s consecutive
             // `rem` (a tile's 16 columns = one 128-byte run): 16 coalesced loads replace the 15-multiplication chain
 #pragma unroll
             for (int ip = 0; ip < CNT; ip++) {
                 const int i = brev(ip, LOG_CNT);
                 const uint32_t kp = k0 + step_k * (uint32_t)ip;
-                dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(vals[i], p.tw_tab[((uint64_t)kp << log_s) + r32]);
+                dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(val(i), p.tw_tab[((uint64_t)kp << log_s) + r32]);
             }
             return;
         }
@@ -280,14 +319,18 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
         for (int ip = 0; ip < CNT; ip++) {
             const int i = brev(ip, LOG_CNT);                 // register holding output digit ip
             const uint32_t kp = k0 + step_k * (uint32_t)ip;
-            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(vals[i], cur);
+#ifdef NTT_EXPERIMENT_NO_CHAIN    // timing experiments only
+            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val(i) ^ cur ^ stp;
+#else
+            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(val(i), cur);
             if (ip + 1 < CNT) cur = F::mul(cur, stp);
+#endif
         }
     };
 
     if constexpr (B == 1) {
         if constexpr (!LAST) {
-            emit_progression(x, 0u, 1u, std::integral_constant<int, LOG_A>{});
+            emit_progression([&](int i) { return x[i]; }, 0u, 1u, std::integral_constant<int, LOG_A>{});
         } else {
 #pragma unroll
             for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
@@ -302,34 +345,75 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                 if (!LAST) y[bb] = lds[idx_nl(ka, bb * TC + t2)];
                 else y[bb] = lds[idx_l(ka, t2, bb)];
             }
-            dft_dif<F, LOG_B>(y, p.w16);
-            if constexpr (!LAST) {
-                emit_progression(y, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
-            } else {
+            if constexpr (F::USE_L24) {
+                typedef l24::Dft<LOG_B> DB;
+                int32_t v[DB::NV];
 #pragma unroll
-                for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+                for (int bb = 0; bb < B; bb++) DB::load(v, bb, y[bb]);
+#ifndef NTT_EXPERIMENT_NO_DFT
+                DB::run(v);
+#endif
+                if constexpr (TWTAB) {
+                    // inter-pass twiddles from the L2-resident table, kept in the same four-word form: multiply, fold, store
+                    const uint32_t r32 = (uint32_t)rem;
+#pragma unroll
+                    for (int ip = 0; ip < B; ip++) {
+                        const int i = brev(ip, LOG_B);
+                        const uint32_t kp = (uint32_t)ka + (uint32_t)A * (uint32_t)ip;
+                        uint32_t yl[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) yl[q] = DB::limb(v, i, q);
+                        const T *w = p.tw_tab + 4 * (((uint64_t)kp << log_s) + r32);
+                        dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = l24::fold(l24::mul4(yl, w[0], w[1], w[2], w[3]));
+                    }
+                } else {
+                    // leave the limb form one element at a time, right where the value is consumed.  The last pass stores these
+                    // words (or multiplies them by a canonical factor): below p.  The progression multiplies them by canonical
+                    // twiddles, and the Montgomery reduction accepts any 64-bit word: lazy is enough.
+                    auto out = [&](int i) -> T {
+                        uint32_t yl[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) yl[q] = DB::limb(v, i, q);
+                        return LAST ? l24::fold(l24::mul4_one(yl)) : l24::fold_lazy(l24::mul4_one(yl));
+                    };
+                    if constexpr (!LAST) {
+                        emit_progression(out, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < B; i++) emit(out(i), (uint32_t)(ka + A * brev(i, LOG_B)));
+                    }
+                }
+            } else {
+                dft_dif<F, LOG_B>(y, p.w16);
+                if constexpr (!LAST) {
+                    emit_progression([&](int i) { return y[i]; }, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
+                } else {
+#pragma unroll
+                    for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+                }
             }
         }
     }
 }
 
 template <class F, int LA, int LB>
-auto pick(bool last) -> void (*)(PassParams<typename F::T>) {
+auto pick(bool last, bool twtab) -> void (*)(PassParams<typename F::T>) {
     typedef void (*fn)(PassParams<typename F::T>);
-    return last ? (fn)ntt_pass<F, LA, LB, true> : (fn)ntt_pass<F, LA, LB, false>;
+    if (last) return (fn)ntt_pass<F, LA, LB, true, false>;
+    return twtab ? (fn)ntt_pass<F, LA, LB, false, true> : (fn)ntt_pass<F, LA, LB, false, false>;
 }
 
 template <class F>
-auto kernel_for(uint32_t r, bool last) -> void (*)(PassParams<typename F::T>) {
+auto kernel_for(uint32_t r, bool last, bool twtab) -> void (*)(PassParams<typename F::T>) {
     switch (r) {
-        case 1: return pick<F, 1, 0>(last);
-        case 2: return pick<F, 1, 1>(last);
-        case 3: return pick<F, 2, 1>(last);
-        case 4: return pick<F, 2, 2>(last);
-        case 5: return pick<F, 3, 2>(last);
-        case 6: return pick<F, 3, 3>(last);
-        case 7: return pick<F, 4, 3>(last);
-        default: return pick<F, 4, 4>(last);
+        case 1: return pick<F, 1, 0>(last, twtab);
+        case 2: return pick<F, 1, 1>(last, twtab);
+        case 3: return pick<F, 2, 1>(last, twtab);
+        case 4: return pick<F, 2, 2>(last, twtab);
+        case 5: return pick<F, 3, 2>(last, twtab);
+        case 6: return pick<F, 3, 3>(last, twtab);
+        case 7: return pick<F, 4, 3>(last, twtab);
+        default: return pick<F, 4, 4>(last, twtab);
     }
 }
 
@@ -364,7 +448,17 @@ __global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename 
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >> log_total) return;
     const uint32_t kp = idx >> log_s, rem = idx & ((1u << log_s) - 1);
-    out[idx] = series_at32<F>(w_lo, w_hi, w_log_lo, (kp * rem) << log_mult);
+    const typename F::T w = series_at32<F>(w_lo, w_hi, w_log_lo, (kp * rem) << log_mult);
+    if constexpr (F::USE_L24) {
+        // rows of four plain-integer words w T^k mod p (l24.cuh); the series tables hold Montgomery residues
+        const uint64_t c = gl::to_int(w);
+        out[4 * (uint64_t)idx + 0] = c;
+        out[4 * (uint64_t)idx + 1] = gl::mul_pow2<24>(c);
+        out[4 * (uint64_t)idx + 2] = gl::mul_pow2<48>(c);
+        out[4 * (uint64_t)idx + 3] = gl::mul_pow2<72>(c);
+    } else {
+        out[idx] = w;
+    }
 }
 }  // namespace
 
@@ -374,12 +468,15 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
     typedef typename F::T T;
     *out = nullptr;
     const uint32_t log_total = r + log_s;
-    if (NTT_TW_TABLE_MAX_LOG == 0 || log_total > NTT_TW_TABLE_MAX_LOG) return WF_OK;
+    // f64 keeps four words per twiddle (l24.cuh): the same byte budget is one entry-doubling earlier; single-step passes
+    // (radix 2) have no limb form of the table multiplication
+    const uint32_t max_log = F::USE_L24 ? NTT_TW_TABLE_MAX_LOG - 1 : NTT_TW_TABLE_MAX_LOG;
+    if (NTT_TW_TABLE_MAX_LOG == 0 || log_total > max_log || (F::USE_L24 && log_b_for(r) == 0)) return WF_OK;
     auto key = std::make_tuple((int)F::ID, L, r, log_s, log_mult);
     auto it = ctx->pass_twiddles.find(key);
     if (it == ctx->pass_twiddles.end()) {
         void *d;
-        WF_HIP(hipMalloc(&d, sizeof(T) << log_total));
+        WF_HIP(hipMalloc(&d, (sizeof(T) * (F::USE_L24 ? 4 : 1)) << log_total));
         ctx->owned.push_back(d);
         const uint32_t total = 1u << log_total;
         hipLaunchKernelGGL(pass_twiddle_table_kernel<F>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, (const T *)om.d_lo, (const T *)om.d_hi,
@@ -410,6 +507,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     p.w_log_lo = om.log_lo;
     void *w256, *w16;
     WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16));
+    if constexpr (F::USE_L24) WF_TRY(wf_get_w256_4form<HF>(ctx, HF::from_u64(1), &w256));
     p.w256 = (const T *)w256;
     p.w16 = (const T *)w16;
     p.pre_lo = (const T *)job.pre_lo;
@@ -475,7 +573,8 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         p.w256 = (const T *)w256;
         if (last && job.has_post_const && log_b_for(r) > 0) {
             void *ws;
-            WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
+            if constexpr (F::USE_L24) WF_TRY(wf_get_w256_4form<HF>(ctx, HF::from_internal(p.post_const), &ws));
+            else WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
             p.w256 = (const T *)ws;
             p.scale_in_w256 = 1;
         }
@@ -496,7 +595,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         }
         const uint64_t blocks = (total_cols + Tc - 1) / Tc;
         if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
-        auto k = kernel_for<F>(r, last);
+        auto k = kernel_for<F>(r, last, p.tw_tab != nullptr);
         wf_prof_begin(ctx, last ? "ntt_pass_last" : "ntt_pass");
         hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
         wf_prof_end(ctx);

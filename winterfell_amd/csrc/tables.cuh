@@ -110,6 +110,34 @@ static int wf_get_scaled_w256(wf_ctx *ctx, typename HF::T c, void **out) {
     return WF_OK;
 }
 
+// f64 passes (l24.cuh): rows of four plain-integer words  c * omega_256^e * T^k mod p,  k < 4, T = 2^24, e < 256 (c canonical;
+// c = 1 for the plain intra-pass twiddles, 1/n for the last pass of an inverse transform)
+template <class HF>
+static int wf_get_w256_4form(wf_ctx *ctx, typename HF::T c, void **out) {
+    typedef typename HF::T T;
+    static_assert(sizeof(T) == 8, "four-word twiddle rows exist for the 64-bit Goldilocks field only");
+    const auto key = std::make_tuple((int)HF::Dev::ID, (uint64_t)c, (uint64_t)0);
+    auto it = ctx->w256_4form.find(key);
+    if (it == ctx->w256_4form.end()) {
+        std::vector<T> h(256 * 4);
+        const T w = HF::root_of_unity(8);
+        T cur = c;
+        for (int i = 0; i < 256; i++) {
+            T f = cur;
+            for (int k = 0; k < 4; k++) {
+                h[4 * i + k] = f;
+                f = HF::mulmod(f, (T)1 << 24);
+            }
+            cur = HF::mulmod(cur, w);
+        }
+        void *p;
+        WF_TRY(wf_upload(ctx, h, &p));
+        it = ctx->w256_4form.emplace(key, p).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
 // LDE pre-scale tables: for coset u (rows u + b*m of the LDE), series (offset * g^u)^j, j < n, g = omega_{n*b}
 template <class HF>
 static int wf_get_lde_tables(wf_ctx *ctx, typename HF::T offset_canon, uint32_t log_n, uint32_t log_b, wf_ctx::LdeTables *out,

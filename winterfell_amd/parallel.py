@@ -26,7 +26,7 @@ def column_partitions(num_cols, num_partitions, hash_rate=1, ext_degree=1):
     air/src/options.rs:428-444).  Returns [(c0, c1), ...]; its length is the actual number of partitions."""
     if num_partitions == 1:
         return [(0, num_cols)]
-    ps = max(-(-num_cols // num_partitions), hash_rate // ext_degree)
+    ps = max(-(-num_cols // num_partitions), (hash_rate & 0xFF) // ext_degree)   # `hash_rate as u8`, options.rs:414-418
     return [(c0, min(c0 + ps, num_cols)) for c0 in range(0, num_cols, ps)]
 
 
@@ -115,10 +115,11 @@ def sharded_commit(backend, trace_shard, domain, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     polys, lde, digests = backend.lde_and_partition_digests(trace_shard, domain)
     if world == 1:
-        gathered = digests.view(-1, 1, 32)
+        # PartitionOptions(1, _): partition_size == num_cols, so the leaf IS the row hash (row_matrix.rs:193-203) — no
+        # merge_many over a single digest
+        leaves = digests.reshape(-1, 32)
     else:
-        gathered = exchange_partition_digests(digests, group)
-    leaves = backend.merge_many_rows(gathered)
+        leaves = backend.merge_many_rows(exchange_partition_digests(digests, group))
     nodes = backend.merkle_nodes(leaves)
     sub_root = nodes[1] if leaves.shape[0] > 1 else nodes[0]
     if world == 1:

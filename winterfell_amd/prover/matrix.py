@@ -15,7 +15,8 @@ class PartitionOptions:
         assert 1 <= num_partitions <= 16, "number of partitions must be in [1, 16]"
         assert 1 <= hash_rate <= 256, "hash rate must be in [1, 256]"
         self.num_partitions = num_partitions
-        self.hash_rate = hash_rate
+        # the reference stores `hash_rate as u8` (air/src/options.rs:414-418), so the permitted value 256 wraps to 0
+        self.hash_rate = hash_rate & 0xFF
 
     def partition_size(self, num_columns, ext_degree=1):
         if self.num_partitions == 1:
@@ -172,7 +173,7 @@ class RowMatrix:
         po = partition_options or PartitionOptions()
         leaves = self.ctx.empty_u8(self.num_rows(), 32)
         self.ctx.call("wf_hash_rows", hasher.HASH_ID, self.field.ID, self.ext_degree, ptr(self.data), self.num_rows(), self.row_width,
-                      self.elements_per_row, po.num_partitions, min(po.hash_rate, 255), ptr(leaves))
+                      self.elements_per_row, po.num_partitions, po.hash_rate or 256, ptr(leaves))
         return leaves
 
     def commit_to_rows(self, hasher, partition_options=None):

@@ -41,7 +41,7 @@ def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partit
     root = np.empty(32, dtype=np.uint8)
     off = f.element_words(int(domain.offset))
     ctx.call("wf_build_trace_commitment", hasher.HASH_ID, f.ID, D, ptr(polys), trace.num_cols(), trace.col_stride(), log_n, log_b,
-             off.ctypes.data_as(ctypes.c_void_p), po.num_partitions, min(po.hash_rate, 255), int(skip_interpolate),
+             off.ctypes.data_as(ctypes.c_void_p), po.num_partitions, po.hash_rate or 256, int(skip_interpolate),
              ptr(lde), ptr(leaves), ptr(nodes), root.ctypes.data_as(ctypes.c_void_p))
     trace_lde = RowMatrix(lde, rw, trace.num_base_cols(), D, ctx, f)
     tree = MerkleTree(hasher, leaves, nodes, ctx)
