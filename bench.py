@@ -26,6 +26,32 @@ import torch
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
 
+def fail(msg, code=2):
+    sys.stderr.write("bench.py: " + msg + "\n")
+    sys.stderr.flush()
+    sys.exit(code)
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: re-run this script as N ranks (one process per GPU) under
+    torch.distributed.run on 127.0.0.1.  Never returns."""
+    backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
+    have = torch.cuda.device_count()
+    if backend == "nccl" and have < args.gpus:
+        fail("--gpus %d asked for but only %d HIP device(s) are visible; refusing to report a %d-GPU number measured on fewer "
+             "devices" % (args.gpus, have, args.gpus))
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (needed by RCCL)
+    import subprocess
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -34,16 +60,27 @@ def main():
     ap.add_argument("--log-n", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="control flow only (launcher, rendezvous, barrier, max-over-ranks reduction): no GPU work, no metric")
     args = ap.parse_args()
+    if args.gpus < 1:
+        fail("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        fail("launched with WORLD_SIZE=%d but --gpus %d: one rank per GPU is the contract" % (world, args.gpus))
     dist = None
     # one process per GPU; WF_BENCH_BACKEND=gloo (with fewer devices than ranks) only exists to exercise the N > 1 control
     # flow on a single-GPU box — the measured configuration is always nccl (= RCCL) with one device per rank
     backend = os.environ.get("WF_BENCH_BACKEND", "nccl")
-    device_index = local_rank % max(torch.cuda.device_count(), 1)
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and not args.dry_run and ndev < world:
+        fail("rank %d: %d HIP device(s) visible, %d ranks: every rank needs its own GPU" % (rank, ndev, world))
+    device_index = local_rank % max(ndev, 1)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -51,6 +88,24 @@ def main():
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
         else:
             dist.init_process_group(backend=backend)
+        if dist.get_world_size() != args.gpus:
+            fail("process group has %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
+    if args.dry_run:
+        # the N > 1 control flow without a GPU: rendezvous, barrier on both sides of the timed region, MAX over ranks, one line
+        t0 = time.perf_counter()
+        if dist is not None:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0 + 1e-3 * (rank + 1)
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.barrier()
+            assert float(t.item()) >= elapsed
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "f64 NTT elements/s", "value": None, "unit": "elements/s", "n_gpus": world, "dry_run": True,
+                              "backend": backend if world > 1 else None}))
+        return
     torch.cuda.set_device(device_index)
     local_rank = device_index
 
@@ -243,7 +298,8 @@ def main():
         # correction + WRITE_SIZE, summed over the transform's launches); only valid for the profiled size
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01", "bench_pmc_summary.json")) as f:
+            pmc_path = next(pth for pth in (os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json") for r in ("r02", "r01")) if os.path.exists(pth))
+            with open(pmc_path) as f:
                 pm = json.load(f)["ntt_2^24_f64"]
             if args.log_n == 24:
                 traffic = pm["hbm_bytes_per_transform"]
@@ -251,7 +307,7 @@ def main():
             traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/r01/bench_pmc_summary.json)",
+            "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/<round>/bench_pmc_summary.json)",
             "limiter": "VALU issue (SQ_ACTIVE_INST_VALU x 4 cycles = 0.8 of the SIMD-cycles of a launch at the nominal 2.4 GHz; HBM traffic = 1.0x the data per pass; see DESIGN.md section 5)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
@@ -334,32 +390,85 @@ def main():
                 pr.build_layers(_Chan(), ev)
 
             ex["fri_build_layers_ms_2^24_quad_fold4_blake3"] = timed(fri_run, 3)
+
+            # ---- HBM rooflines of the other reported rates: algorithmic bytes (SURVEY 8d / BASELINE.md section 4) over the
+            # summed kernel durations (HIP events on the launch stream, wf_prof_*) of one call ----
+            def kernel_ms(fn, reps=3):
+                fn()
+                ctx.prof_enable(True)
+                for _ in range(reps):
+                    fn()
+                prof = ctx.prof_collect()
+                ctx.prof_enable(False)
+                return sum(ms for _, ms in prof.values()) / reps, {k: round(ms * 1e3 / reps, 1) for k, (c, ms) in prof.items()}
+
+            def roof(alg_bytes, ms, kernels_us, what):
+                gbs = alg_bytes / (ms * 1e-3) / 1e9
+                return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "algorithmic_bytes": alg_bytes, "kernel_ms": ms, "kernels_us_per_call": kernels_us, "what": what}
+
+            rl = {}
+            cm = prover.ColMatrix(ctx.to_device(rng.integers(0, fields.M, (tc, tn), dtype=np.uint64)))
+            dom = prover.StarkDomain(tn, tb)
+            ms, ks = kernel_ms(lambda: prover.build_trace_commitment(crypto.Blake3_256, cm, dom))
+            rl["lde_commit_2^20x4_b8_f64_blake3"] = roof(tn * tc * 8 * (2 + tb) + 64 * tb * tn, ms, ks,
+                                                         "n c s (2 + b) + 64 b n: read trace, write polys + LDE + leaves + nodes")
+            lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
+            ms, ks = kernel_ms(lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))
+            rl["merkle_blake3_2^23_leaves"] = roof(64 * (1 << 23), ms, ks, "64 B per leaf: read leaves, write nodes")
+            del lv
+            fri_bytes, ln = 0, 1 << 24
+            while ln > 256:                      # FriOptions(blowup 8, folding 4, remainder degree 31): layers down to 2^8 evaluations
+                fri_bytes += ln * 16 + (ln // 4) * 16 + 64 * (ln // 4)
+                ln //= 4
+            ms, ks = kernel_ms(fri_run, 2)
+            rl["fri_build_layers_2^24_quad_fold4_blake3"] = roof(fri_bytes, ms, ks,
+                                                                 "per layer: len e (read) + len/4 e (folded) + 64 len/4 (leaves + nodes)")
+            out["rooflines"] = rl
             del ev
             if sharded:
                 ex.update(sharded)
             out["extra"] = ex
 
         if not args.no_cpu_baseline:
-            # ---- CPU baseline: the oracle's restatement of the reference's concurrent algorithm ----
+            # ---- CPU baseline (rank 0, N = 1 semantics): the oracle's OpenMP restatement of the reference's `concurrent`
+            # (Rayon) algorithms, on this host.  As in math/benches/fft.rs the twiddles are computed once, outside the timed
+            # body; the transform runs in place at the bench's own size.  The reference's 4-step
+            # transposes are single-threaded (math/src/fft/concurrent.rs:177-218) and so are ours.
             import oracle
-            ncores = os.cpu_count() or 1
-            cpu_log_n = min(args.log_n, 22)
-            cn = 1 << cpu_log_n
-            cp = host[:cn].copy()
-            oracle.get_twiddles(16)  # load the library
+            nthreads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+            cn = n
+            cp = host.copy()
+            tw, itw = oracle.get_twiddles(cn), oracle.get_inv_twiddles(cn)
+            oracle.evaluate_poly(cp[:1 << 16], par=True)          # load the library, spin up the OpenMP pool
             t1 = time.perf_counter()
             reps_cpu = 0
             while reps_cpu < 1 or (time.perf_counter() - t1 < 10.0 and reps_cpu < 8):
-                ev = oracle.evaluate_poly(cp, par=True)
-                cp2 = oracle.interpolate_poly(ev, par=True)
+                oracle.evaluate_poly(cp, par=True, twiddles=tw, inplace=True)
+                oracle.interpolate_poly(cp, par=True, twiddles=itw, inplace=True)
                 reps_cpu += 1
             cpu_s = time.perf_counter() - t1
-            assert np.array_equal(cp2, cp)
-            out["cpu_baseline"] = {
-                "value": 2.0 * cn * reps_cpu / cpu_s, "unit": "elements/s", "cores": ncores, "kind": "port",
-                "sample": "%d x (evaluate_poly + interpolate_poly) at 2^%d points, OpenMP restatement of "
-                          "math/src/fft/concurrent.rs (includes twiddle generation)" % (reps_cpu, cpu_log_n),
+            assert np.array_equal(cp, host)
+            cpu = {
+                "value": 2.0 * cn * reps_cpu / cpu_s, "unit": "elements/s", "cores": nthreads, "kind": "port",
+                "sample": "%d x (evaluate_poly + interpolate_poly) in place at 2^%d points, twiddles precomputed; OpenMP restatement of "
+                          "math/src/fft/concurrent.rs (oracle/fft_f64.c), %d threads" % (reps_cpu, args.log_n, nthreads),
             }
+            if not args.no_extra:
+                # the second metric beside its CPU path: trace LDE + commit (spans extend_execution_trace +
+                # compute_execution_trace_commitment, trace_lde/default/mod.rs:258-278) and the Merkle build, BLAKE3 (portable C)
+                tr = rng.integers(0, fields.M, (4, 1 << 20), dtype=np.uint64)
+                t1 = time.perf_counter()
+                oracle.build_trace_commitment(0, tr, 8, fields.new(7), par=True)
+                cpu["lde_commit_ms_2^20x4_b8_f64_blake3"] = (time.perf_counter() - t1) * 1e3
+                lvh = rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8)
+                t1 = time.perf_counter()
+                oracle.merkle_build(0, lvh, par=True)
+                cpu["merkle_blake3_leaves_per_s_2^23"] = (1 << 23) / (time.perf_counter() - t1)
+                cpu["extras_note"] = ("one call each (buffers allocated inside the call); concurrent interpolate_columns + 8-column-segment "
+                                      "LDE + commit_to_rows + subtree-per-thread Merkle (oracle/commit.c), portable-C BLAKE3 (the Rust "
+                                      "crate is AVX2/AVX-512)")
+            out["cpu_baseline"] = cpu
         print(json.dumps(out))
 
     if dist is not None:

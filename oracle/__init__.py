@@ -146,20 +146,22 @@ def permute_index(size, index):
     return lib().or_permute_index(_u64(size), _u64(index))
 
 
-def evaluate_poly(p, D=1, par=False):
-    """fft::evaluate_poly — natural-order coefficients -> natural-order evaluations (copy)."""
-    v = _u64arr(p).copy()
+def evaluate_poly(p, D=1, par=False, twiddles=None, inplace=False):
+    """fft::evaluate_poly — natural-order coefficients -> natural-order evaluations (a copy unless inplace).
+    `twiddles` = get_twiddles(n) computed by the caller (the reference computes them once per domain and its benches keep
+    them out of the timed body, math/benches/fft.rs)."""
+    v = _u64arr(p) if inplace else _u64arr(p).copy()
     n = v.size // D
-    tw = get_twiddles(n)
+    tw = get_twiddles(n) if twiddles is None else twiddles
     fn = lib().or_f64_evaluate_poly_par if par else lib().or_f64_evaluate_poly
     fn(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw))
     return v
 
 
-def interpolate_poly(ev, D=1, par=False):
-    v = _u64arr(ev).copy()
+def interpolate_poly(ev, D=1, par=False, twiddles=None, inplace=False):
+    v = _u64arr(ev) if inplace else _u64arr(ev).copy()
     n = v.size // D
-    tw = get_inv_twiddles(n)
+    tw = get_inv_twiddles(n) if twiddles is None else twiddles
     fn = lib().or_f64_interpolate_poly_par if par else lib().or_f64_interpolate_poly
     fn(_ptr(v), _u64(n), ctypes.c_uint(D), _ptr(tw))
     return v

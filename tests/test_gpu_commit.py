@@ -216,6 +216,25 @@ def test_full_size_lde_commit_properties(wf, oracle):
     assert not nodes[0].any()
 
 
+@pytest.mark.parametrize("hname", ["Blake3_256", "Rp64_256"])
+def test_full_size_lde_commit_output_for_output(wf, oracle, hname):
+    """BASELINE configs[2] shape at full size (2^20 rows x 4 f64 columns, blowup 8), word for word: trace polynomials, the
+    whole 2^23-row LDE matrix, every leaf, every Merkle node and the root of wf_build_trace_commitment against the CPU
+    oracle's restatement of DefaultTraceLde::new (prover/src/trace/trace_lde/default/mod.rs:245-282, concurrent variants)."""
+    ctx, crypto, prover, fields = wf
+    hasher = getattr(crypto, hname)
+    n, c, b = 1 << 20, 4, 8
+    trace = oracle.f64_from_int(rand_field(4242, n * c)).reshape(c, n)
+    lde, tree, polys = prover.build_trace_commitment(hasher, prover.ColMatrix(trace), prover.StarkDomain(n, b))
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(_hid(crypto, hasher), trace, b, fields.new(7), par=True)
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    got = lde.to_host()
+    assert got.shape == o_lde.shape and np.array_equal(got, o_lde), "lde: %d words differ" % int(np.count_nonzero(got != o_lde))
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"
+    assert np.array_equal(tree.root(), o_nodes[1])
+
+
 @pytest.mark.parametrize("hname,world", [("Blake3_256", 4), ("Rp64_256", 2), ("Blake3_256", 8)])
 def test_column_sharded_commitment_emulated_on_one_gpu(wf, oracle, hname, world):
     """G logical column shards on one GPU (same kernels, same shard math as the multi-process path)

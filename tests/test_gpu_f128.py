@@ -174,8 +174,10 @@ def test_full_size_trace_commitment_properties(wf, oracle, log_n, cols, parts):
         lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace, field=f),
                                                          prover.StarkDomain(n, b, field=f), po)
         torch.cuda.synchronize()
-    except (RuntimeError, Exception) as e:   # noqa: BLE001
-        if "out of memory" in str(e).lower() or "HIP" in str(e):
+    except RuntimeError as e:
+        # only a genuine allocation failure may skip (the 64-column case needs ~80 GiB); a kernel fault must fail the test
+        lib_oom = getattr(e, "status", None) == 6 and ctx.lib.wf_last_hip_error(ctx.handle) == 2   # WF_ERR_HIP + hipErrorOutOfMemory
+        if "out of memory" in str(e).lower() or lib_oom:
             pytest.skip("not enough free HBM on this box for the full-size case: %s" % str(e)[:80])
         raise
     assert lde.num_rows() == N and lde.row_width == 8 * ((cols + 7) // 8)
@@ -222,3 +224,22 @@ def test_full_size_trace_commitment_properties(wf, oracle, log_n, cols, parts):
     assert np.array_equal(cur, ctx.to_host(nodes_dev[1]))
     del lde, tree, polys, trace
     torch.cuda.empty_cache()
+
+
+def test_rescue_example_trace_commitment_output_for_output(wf, oracle):
+    """BASELINE configs[2] as the reference ships it: examples::rescue (f128, seed [42, 43], chain 2^16 -> 2^20 x 4 trace,
+    examples/src/rescue/mod.rs:71, prover.rs:30-63), blowup 8, Blake3_256 — trace polynomials, the whole LDE matrix, every
+    leaf and every node of the trace commitment against the CPU oracle, word for word."""
+    ctx, crypto, prover, _, fft, fields = wf
+    f, of = fields.f128, oracle.f128
+    trace = of.rescue_build_trace([42, 43], 1 << 16)
+    n, b = 1 << 20, 8
+    assert trace.shape == (4, 2 * n)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace, field=f),
+                                                     prover.StarkDomain(n, b, field=f))
+    o_polys, o_lde, o_leaves, o_nodes = of.build_trace_commitment(0, trace, b, 3)          # StarkField::GENERATOR = 3
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    got = lde.to_host()
+    assert got.shape == o_lde.shape and np.array_equal(got, o_lde), "lde"
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"

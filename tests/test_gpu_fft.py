@@ -144,6 +144,31 @@ def test_full_size_properties(wf, oracle, log_n):
         assert es[k] == oracle.f64_add(int(host[k]), int(hb[k]))
 
 
+@pytest.mark.parametrize("log_n", [22, 24])
+def test_full_size_output_for_output(wf, oracle, log_n):
+    """BASELINE configs[1] at its own sizes, word for word: the whole 2^22 / 2^24-point evaluate_poly and interpolate_poly
+    outputs against the CPU oracle's restatement of the reference's concurrent path (math/src/fft/mod.rs:85-112,264-295,
+    concurrent.rs), plus the coset variants the LDE uses (mod.rs:168-211,351-386)."""
+    ctx, fft, fields = wf
+    n = 1 << log_n
+    a = oracle.f64_from_int(rand_field(31000 + log_n, n))
+    ev = ctx.to_host(fft.evaluate_poly(ctx.to_device(a)))
+    want = oracle.evaluate_poly(a, par=True)
+    assert np.array_equal(ev, want), "evaluate_poly differs at %d positions" % int(np.count_nonzero(ev != want))
+    ip = ctx.to_host(fft.interpolate_poly(ctx.to_device(a)))
+    want = oracle.interpolate_poly(a, par=True)
+    assert np.array_equal(ip, want), "interpolate_poly differs at %d positions" % int(np.count_nonzero(ip != want))
+    if log_n == 22:
+        # coset transforms at full size: evaluate over offset * <g_{8n}> (blowup 8 of a 2^19-point polynomial = 2^22 outputs)
+        # and interpolate_poly_with_offset of the 2^22-point vector
+        poly = a[: n // 8].copy()
+        off = fields.new(7)
+        got = fft.evaluate_poly_with_offset(poly.copy(), None, off, 8)
+        assert np.array_equal(got, oracle.evaluate_poly_with_offset(poly, off, 8))
+        got = fft.interpolate_poly_with_offset(a.copy(), None, off)
+        assert np.array_equal(got, oracle.interpolate_poly_with_offset(a, off))
+
+
 @pytest.mark.parametrize("log_n", [26, 27])
 def test_beyond_baseline_sizes(wf, oracle, log_n):
     """Sizes above BASELINE's 2^24 (1 GiB vector at 2^27; four passes at 2^26+): round trip and Horner spot values."""
@@ -277,3 +302,23 @@ def test_power_series_and_batch_inversion(wf, fname):
     vals[1] = f.M - 1
     got = f.to_ints(utils.batch_inversion(f.from_ints(vals), field=f))
     assert got == [pow(v, f.M - 2, f.M) if v else 0 for v in vals]
+
+
+def test_follows_torchs_current_stream(wf, oracle):
+    """The context re-binds to torch's current stream on every call: library kernels issued inside `with torch.cuda.stream(s)`
+    stay ordered with the torch work (clone / copies) issued on that stream around them."""
+    ctx, fft, fields = wf
+    import torch
+    n = 1 << 16
+    a = oracle.f64_from_int(rand_field(555, n))
+    want = oracle.evaluate_poly(a)
+    s = torch.cuda.Stream(device=ctx.device)
+    for _ in range(5):
+        with torch.cuda.stream(s):
+            d = ctx.to_device(a)
+            e = fft.evaluate_poly(d.clone())
+            back = fft.interpolate_poly(e.clone())
+            got, rt = ctx.to_host(e), ctx.to_host(back)
+        assert np.array_equal(got, want) and np.array_equal(rt, a)
+    torch.cuda.synchronize()
+    assert np.array_equal(ctx.to_host(fft.evaluate_poly(ctx.to_device(a))), want)     # and back on the default stream

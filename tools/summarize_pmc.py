@@ -19,19 +19,27 @@ for path in glob.glob("%s/pmc_*/%s_counter_collection.csv" % (raw, rnd)):
 kernels = {k: {c: {"launches": len(v), "avg": sum(v) / len(v)} for c, v in sorted(cs.items())} for k, cs in sorted(acc.items())}
 
 
-def traffic(sub, last):
+import re
+
+
+def traffic(last, twtab):
+    """(2 x FETCH_SIZE + WRITE_SIZE) bytes per launch of the radix-256 f64 pass kernel with these template flags
+    (ntt_pass<F64, LOG_A, LOG_B, LAST, TWTAB>)."""
     tot = 0.0
     for k, cs in kernels.items():
-        is_last = ", true>" in k
-        if "ntt_pass<F64" in k and is_last == last and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+        m = re.search(r"ntt_pass<F64, 4, 4, (true|false), (true|false)>", k)
+        if m and (m.group(1) == "true") == last and (m.group(2) == "true") == twtab and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             tot = (2 * cs["FETCH_SIZE"]["avg"] + cs["WRITE_SIZE"]["avg"]) * 1024
     return tot
 
 
-p, l = traffic("ntt_pass", False), traffic("ntt_pass", True)
+# a 2^24-point transform = progression pass (first) + table pass (second) + last pass
+p0, p1, l = traffic(False, False), traffic(False, True), traffic(True, False)
+p = p0
 out = {
     "note": "rocprofv3 --pmc, separate passes for FETCH_SIZE / WRITE_SIZE / SQ_*; bench.py --steps 3 --log-n 24; FETCH_SIZE doubled per the gfx950 correction",
-    "ntt_2^24_f64": {"ntt_pass_bytes_per_launch": p, "ntt_pass_last_bytes_per_launch": l, "hbm_bytes_per_transform": 2 * p + l,
+    "ntt_2^24_f64": {"ntt_pass_progression_bytes_per_launch": p0, "ntt_pass_table_bytes_per_launch": p1, "ntt_pass_last_bytes_per_launch": l,
+                     "hbm_bytes_per_transform": p0 + p1 + l,
                      "algorithmic_bytes_per_transform": 268435456},
     "kernels": kernels,
 }

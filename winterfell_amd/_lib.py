@@ -130,9 +130,14 @@ class Context:
         _live.append(self)
 
     def use_torch_stream(self):
+        """Bind the library's launches to torch's CURRENT stream of this device.  Re-checked on every call(): torch work
+        issued around the library calls (empty / clone / reductions / copies) runs on whatever stream is current, e.g.
+        inside `with torch.cuda.stream(s)`, and must stay ordered with the kernels."""
         torch = _torch()
-        s = torch.cuda.current_stream(self.device)
-        _check(self.lib.wf_ctx_set_stream(self.handle, _vp(s.cuda_stream)), "wf_ctx_set_stream")
+        s = torch.cuda.current_stream(self.device).cuda_stream
+        if s != getattr(self, "_bound_stream", None):
+            _check(self.lib.wf_ctx_set_stream(self.handle, _vp(s)), "wf_ctx_set_stream")
+            self._bound_stream = s
 
     def sync(self):
         _check(self.lib.wf_ctx_sync(self.handle), "wf_ctx_sync")
@@ -182,6 +187,7 @@ class Context:
         return out
 
     def call(self, name, *args):
+        self.use_torch_stream()
         _check(getattr(self.lib, name)(self.handle, *args), name)
 
 
