@@ -1,7 +1,7 @@
 // The reference's `fib-small` example (examples/src/fibonacci/fib_small) end to end through the C++ host layer
 // (include/winterfell_hip.hpp): the steps of Prover::generate_proof (prover/src/lib.rs:275-492) with every data-parallel step
-// on the device and the Fiat-Shamir coin / channel as host logic.  The transcript is the one winterfell_amd.prover.prove()
-// produces (same context elements, same draw order), so for equal inputs both host layers print the same roots, nonce and
+// on the device and the Fiat-Shamir coin / channel as host logic.  The transcript is the reference's (coin seeded with
+// Context::to_elements() ++ public inputs, same draw order) and the one winterfell_amd.prover.prove() produces, so for equal inputs both host layers print the same roots, nonce and
 // query positions — tests/test_gpu_cpp_host.py checks exactly that.
 //
 //   g++ -O2 -std=c++17 -Iinclude examples/fib_small.cpp -Lwinterfell_amd -lwinterfell_hip -o examples/fib_small.bin
@@ -138,10 +138,10 @@ int main(int argc, char **argv) {
         wf::ColMatrix cm{wf::DeviceBuffer(ctx, trace), F, 2, 1, n};
         ctx.sync();
         const auto t0 = std::chrono::steady_clock::now();
-        // coin seed: the context elements + public inputs (winterfell_amd/prover/channel.py)
+        // coin seed = hash_elements(Context::to_elements() ++ PublicInputs::to_elements()), the reference's encoding
+        // (prover/src/channel.rs:57-75; fib_small's public input is the result element, 3 assertions + 2 transition constraints)
         std::vector<uint64_t> seed_e;
-        for (uint64_t v : {(uint64_t)2, n, blowup, (uint64_t)num_queries, (uint64_t)grinding, (uint64_t)D, (uint64_t)folding, (uint64_t)rem_deg, (uint64_t)5})
-            seed_e.push_back(to_mont(v));
+        for (uint64_t v : wf::context_to_elements_f64(2, n, P, 5, D, folding, rem_deg, (uint32_t)blowup, grinding, num_queries)) seed_e.push_back(to_mont(v));
         seed_e.push_back(result);
         Coin coin(ctx, hash, seed_e);
         // 1. main trace commitment

@@ -386,6 +386,19 @@ inline TraceCommitment build_trace_commitment(Hash h, const ColMatrix &trace, ui
 }
 
 // ---- fri::FriProver (commit phase) -------------------------------------------------------------------------------------------
+// Context::to_elements (air/src/proof/context.rs:106-137) as canonical integers — what the prover channel seeds its coin with,
+// followed by PublicInputs::to_elements() (prover/src/channel.rs:57-75).  TraceInfo::to_elements (air/src/air/trace_info.rs:209-238):
+// segment widths packed 8 bits each, then the trace length; the field modulus' little-endian bytes split into two elements;
+// the number of constraints; ProofOptions::to_elements (air/src/options.rs:294-305) with FieldExtension None / Quadratic / Cubic
+// = 1 / 2 / 3 = the extension degree.  (64-bit fields; no auxiliary segment, no trace metadata: the built-in AIRs have neither.)
+inline std::vector<uint64_t> context_to_elements_f64(uint32_t main_width, uint64_t trace_length, uint64_t modulus, uint32_t num_constraints,
+                                                     uint32_t ext_degree, uint32_t fri_folding_factor, uint32_t fri_remainder_max_degree,
+                                                     uint32_t blowup_factor, uint32_t grinding_factor, uint32_t num_queries) {
+    const uint64_t options = ((((((uint64_t)ext_degree << 8) | fri_folding_factor) << 8) | fri_remainder_max_degree) << 8) | blowup_factor;
+    return {(uint64_t)main_width << 8, trace_length & 0xffffffffull, modulus & 0xffffffffull, modulus >> 32, num_constraints, options,
+            grinding_factor, num_queries};
+}
+
 // fri::ProverChannel (fri/src/prover/channel.rs:24-50): the host Fiat-Shamir transcript, supplied by the caller
 struct ProverChannel {
     virtual ~ProverChannel() = default;

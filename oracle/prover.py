@@ -1,0 +1,249 @@
+"""CPU restatement of Prover::generate_proof (prover/src/lib.rs:282-492) for the built-in example AIRs — TEST INFRASTRUCTURE
+(see oracle/__init__.py): the checker the GPU pipeline's proof artefacts are compared with, never part of the product path.
+
+Every numerical step is one of the oracle's C restatements (trace commitment, constraint evaluation, composition polynomial,
+out-of-domain frames, DEEP composition, FRI layers); what this file adds is the Fiat-Shamir transcript in the reference's own
+order and encoding:
+
+  * coin seed = hash_elements(Context::to_elements() ++ PublicInputs::to_elements())        prover/src/channel.rs:57-75
+      Context::to_elements       air/src/proof/context.rs:106-137
+      TraceInfo::to_elements     air/src/air/trace_info.rs:209-238
+      ProofOptions::to_elements  air/src/options.rs:294-305
+      PublicInputs::to_elements  examples/src/rescue/air.rs:45-51 (seed ++ result), fibonacci: the result element,
+                                 vdf: [seed, result]
+  * DefaultRandomCoin (new / reseed / draw / check_leading_zeros / draw_integers)            crypto/src/random/default.rs
+  * ProverChannel (commit_trace, commit_constraints, send_ood_evaluations, coefficient draws with linear batching,
+    grind_query_seed with the SERIAL rule = smallest nonce, get_query_positions)             prover/src/channel.rs:84-185
+
+The coin below is written from the reference independently of winterfell_amd/crypto/random.py (which the product uses), on
+the oracle's own hashers, so that a transcript mismatch between the two shows up as a failed comparison.
+"""
+import numpy as np
+
+import oracle as orc
+
+# FieldExtension discriminants (air/src/options.rs:47-54) coincide with the extension degree
+BLAKE3_256, RP64_256 = 0, 1
+
+
+class Options:
+    """air::ProofOptions, the fields that reach the transcript (air/src/options.rs:88-118)."""
+
+    def __init__(self, num_queries, blowup_factor, grinding_factor, field_extension=1, fri_folding_factor=4, fri_remainder_max_degree=31):
+        self.num_queries, self.blowup_factor, self.grinding_factor = num_queries, blowup_factor, grinding_factor
+        self.field_extension, self.fri_folding_factor, self.fri_remainder_max_degree = field_extension, fri_folding_factor, fri_remainder_max_degree
+
+    def to_elements(self):
+        buf = self.field_extension
+        buf = (buf << 8) | self.fri_folding_factor
+        buf = (buf << 8) | self.fri_remainder_max_degree
+        buf = (buf << 8) | self.blowup_factor
+        return [buf, self.grinding_factor, self.num_queries]
+
+
+def trace_info_to_elements(main_width, trace_length, element_bytes, aux_width=0, num_aux_rands=0, meta=b""):
+    buf = main_width
+    num_aux_segments = 1 if aux_width else 0
+    buf = (buf << 8) | num_aux_segments
+    if num_aux_segments == 1:
+        buf = (buf << 8) | aux_width
+        buf = (buf << 8) | num_aux_rands
+    out = [buf, trace_length & 0xFFFFFFFF]
+    step = element_bytes - 1
+    for i in range(0, len(meta), step):
+        out.append(int.from_bytes(meta[i:i + step], "little"))            # from_bytes_with_padding
+    return out
+
+
+def context_to_elements(modulus, element_bytes, main_width, trace_length, num_constraints, options, **trace_kw):
+    """Canonical integers, in the order of Context::to_elements."""
+    out = trace_info_to_elements(main_width, trace_length, element_bytes, **trace_kw)
+    mb = modulus.to_bytes(element_bytes, "little")                          # StarkField::get_modulus_le_bytes
+    half = len(mb) // 2
+    out += [int.from_bytes(mb[:half], "little"), int.from_bytes(mb[half:], "little")]
+    out.append(num_constraints & 0xFFFFFFFF)
+    return out + options.to_elements()
+
+
+def to_internal(fld, v):
+    """canonical integer -> the field's internal representation (Montgomery for f64, the integer itself for f128)"""
+    return int(orc.f64_new(int(v))) if fld.name == "f64t" else int(v)
+
+
+class Hasher:
+    """ElementHasher over the oracle's byte-level functions, for one base field."""
+
+    def __init__(self, hasher_id, fld):
+        assert hasher_id in (BLAKE3_256, RP64_256)
+        assert hasher_id == BLAKE3_256 or fld.name == "f64t", "Rp64_256 exists over f64 only"
+        self.id, self.fld = hasher_id, fld
+
+    def hash_elements(self, words):
+        w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+        if self.fld.name == "f64t":
+            return orc.hash_elements(self.id, w)
+        return np.frombuffer(orc.blake3(w.tobytes()), dtype=np.uint8).copy()   # f128 is IS_CANONICAL: raw little-endian bytes
+
+    def merge(self, a, b):
+        return orc.merge(self.id, np.stack([np.asarray(a, dtype=np.uint8).reshape(32), np.asarray(b, dtype=np.uint8).reshape(32)]))
+
+    def merge_with_int(self, seed, value):
+        return orc.merge_with_int(self.id, np.asarray(seed, dtype=np.uint8).reshape(32), value)
+
+    def digest_as_bytes(self, d):
+        d = np.asarray(d, dtype=np.uint8).reshape(32)
+        if self.id == BLAKE3_256:
+            return d.tobytes()
+        return orc.f64_to_int(d.view(np.uint64)).tobytes()                  # ElementDigest::as_bytes: canonical words
+
+
+class Coin:
+    """DefaultRandomCoin (crypto/src/random/default.rs:82-248)."""
+
+    def __init__(self, hasher, seed_words):
+        self.h = hasher
+        self.seed = hasher.hash_elements(seed_words)
+        self.counter = 0
+
+    def _next(self):
+        self.counter += 1
+        return self.h.digest_as_bytes(self.h.merge_with_int(self.seed, self.counter))
+
+    def reseed(self, digest):
+        self.seed = self.h.merge(self.seed, digest)
+        self.counter = 0
+
+    def draw(self, D=1):
+        f = self.h.fld
+        nb = 8 * f.W
+        for _ in range(1000):
+            b = self._next()[:D * nb]
+            vals = [int.from_bytes(b[k * nb:(k + 1) * nb], "little") for k in range(D)]
+            if all(v < f.M for v in vals):                                  # E::from_random_bytes -> try_from: every base element canonical
+                return f.pack([to_internal(f, v) for v in vals])
+        raise RuntimeError("FailedToDrawFieldElement(1000)")
+
+    def check_leading_zeros(self, value):
+        head = int.from_bytes(self.h.digest_as_bytes(self.h.merge_with_int(self.seed, value))[:8], "little")
+        return 64 if head == 0 else (head & -head).bit_length() - 1
+
+    def draw_integers(self, num_values, domain_size, nonce):
+        assert domain_size & (domain_size - 1) == 0 and num_values < domain_size
+        self.seed = self.h.merge_with_int(self.seed, nonce)
+        self.counter = 0
+        out = []
+        for _ in range(1000):
+            v = int.from_bytes(self._next()[:8], "little") & (domain_size - 1)
+            out.append(v)
+            if len(out) == num_values:
+                return out
+        raise RuntimeError("FailedToDrawIntegers")
+
+
+# ---- the example AIRs: (AIR id of the oracle's evaluator, width, transition-constraint degrees (base, cycles), builder) ------
+def _degree_eval(base, cycles, n):
+    return base * (n - 1) + sum((n // c) * (c - 1) for c in cycles)
+
+
+def _min_blowup(base, cycles):
+    bound = base + len(cycles) - 1
+    return max(1 if bound <= 1 else 1 << (bound - 1).bit_length(), 2)
+
+
+def example(name, fld, n):
+    """-> dict(air, width, degrees, trace (c, n*W words), assertions [(column, step, value)], pub, exemptions); values are
+    integers in the field's internal representation."""
+    if name == "fib_small":
+        trace = fld.fib_small_build_trace(n)
+        result, one = fld.unpack(trace[1])[n - 1], to_internal(fld, 1)
+        return dict(air=0, width=2, degrees=[(1, ()), (1, ())], trace=trace, assertions=[(0, 0, one), (1, 0, one), (1, n - 1, result)], pub=[result],
+                    exemptions=1)
+    if name == "rescue":
+        assert fld.name == "f128"
+        trace = fld.rescue_build_trace([42, 43], n // 16)
+        t0, t1 = fld.unpack(trace[0]), fld.unpack(trace[1])
+        seed, result = [t0[0], t1[0]], [t0[n - 1], t1[n - 1]]
+        return dict(air=1, width=4, degrees=[(3, (16,))] * 4, trace=trace,
+                    assertions=[(0, 0, seed[0]), (1, 0, seed[1]), (0, n - 1, result[0]), (1, n - 1, result[1])], pub=seed + result, exemptions=1)
+    raise ValueError(name)
+
+
+def prove(name, fld, hasher_id, n, options):
+    """Runs the whole prover on the CPU.  Returns the artefacts a Proof is assembled from, as numpy arrays of internal-form
+    words (roots: 32 bytes)."""
+    ex = example(name, fld, n)
+    h = Hasher(hasher_id, fld)
+    D, W, b = options.field_extension, fld.W, options.blowup_factor
+    ew = D * W
+    width, degrees = ex["width"], ex["degrees"]
+    nt, na = len(degrees), len(ex["assertions"])
+    ce_blowup = max(_min_blowup(*d) for d in degrees)
+    highest = max(_degree_eval(bs, cy, n) for bs, cy in degrees)
+    ncols = max(-(-(highest - (n - ex["exemptions"]) + 1) // n), 1)         # AirContext::num_constraint_composition_columns
+    offset = to_internal(fld, {"f64t": 7, "f128": 3}[fld.name])             # StarkField::GENERATOR
+    # 0. channel: seed the coin with context + public inputs (channel.rs:57-75)
+    ctx_elems = context_to_elements(fld.M, 8 * W, width, n, na + nt, options)
+    coin = Coin(h, fld.pack([to_internal(fld, v) for v in ctx_elems] + list(ex["pub"])))
+    art = {"context_elements": ctx_elems, "pub_inputs": list(ex["pub"]), "coin_seed": coin.seed.copy()}
+    # 1. commit to the main trace segment
+    polys, lde, leaves, nodes = fld.build_trace_commitment(hasher_id, ex["trace"], b, offset)
+    trace_root = nodes[1].copy()
+    coin.reseed(trace_root)
+    # 2. constraint composition coefficients (linear batching: one draw per constraint, transition first), evaluation
+    cc_t = np.stack([coin.draw(D) for _ in range(nt)])
+    cc_b = np.stack([coin.draw(D) for _ in range(na)])
+    assertions = sorted(ex["assertions"], key=lambda a: (0, a[1], a[0]))     # Ord for Assertion: stride, first_step, column
+    comp = fld.evaluate_constraints(ex["air"], lde, lde.shape[1] // W, n, b, ce_blowup, offset, D, cc_t.reshape(-1),
+                                    [(c, s, fld.pack([v])) for c, s, v in assertions], cc_b.reshape(-1))
+    # 3. composition polynomial (interpolate over the ce coset, cut into columns of n coefficients) and its commitment
+    coeffs = fld.interpolate_poly_with_offset(comp, offset, D)
+    assert not coeffs[ncols * n * ew:].any(), "composition polynomial does not fit its columns"
+    cpoly = coeffs[:ncols * n * ew].reshape(ncols, n * ew)
+    col_evals = np.stack([fld.evaluate_poly(cpoly[i], D) for i in range(ncols)])   # so that the commitment routine's interpolation returns cpoly
+    q_polys, q_lde, q_leaves, q_nodes = fld.build_trace_commitment(hasher_id, col_evals, b, offset, D=D)
+    assert np.array_equal(q_polys, cpoly)
+    constraint_root = q_nodes[1].copy()
+    coin.reseed(constraint_root)
+    # 4. out-of-domain point, frames, DEEP composition
+    z = coin.draw(D)
+    g = fld.root_of_unity(n.bit_length() - 1)
+    zg = fld.pack(fld.ext_mul(D, fld.unpack(z), [g] + [0] * (D - 1)))
+    t_cur = fld.evaluate_columns_at(polys, width, z, D, 1)
+    t_next = fld.evaluate_columns_at(polys, width, zg, D, 1)
+    q_cur = fld.evaluate_columns_at(cpoly, ncols, z, D, D)
+    q_next = fld.evaluate_columns_at(cpoly, ncols, zg, D, D)
+    ood = np.concatenate([t_cur.reshape(-1), q_cur.reshape(-1), t_next.reshape(-1), q_next.reshape(-1)])   # merge_ood_evaluations
+    coin.reseed(h.hash_elements(ood))
+    dc_t = np.stack([coin.draw(D) for _ in range(width)])
+    dc_c = np.stack([coin.draw(D) for _ in range(ncols)])
+    deep = fld.deep_compose(polys, width, None, 0, cpoly, ncols, n, D, z, dc_t.reshape(-1), dc_c.reshape(-1), t_cur.reshape(-1), t_next.reshape(-1),
+                            q_cur.reshape(-1), q_next.reshape(-1))
+    deep_evals = fld.evaluate_poly_with_offset(deep, offset, b, D)
+    # 5. FRI commit phase
+    N = options.fri_folding_factor
+    fri_roots, alphas, evals, length = [], [], deep_evals, n * b
+    for _ in range(int(orc.fri_num_layers(n * b, N, b, options.fri_remainder_max_degree))):
+        transposed = fld.transpose_slice(evals, N, D)
+        _, lnodes = fld.fri_layer_commit(hasher_id, transposed, N, D)
+        fri_roots.append(lnodes[1].copy())
+        coin.reseed(lnodes[1])
+        alpha = coin.draw(D)
+        alphas.append(alpha)
+        evals = fld.apply_drp(transposed, N, offset, alpha, D)
+        length //= N
+    rc = fld.interpolate_poly_with_offset(evals, offset, D).reshape(length, ew) if length > 1 else np.asarray(evals).reshape(1, ew)
+    remainder = np.ascontiguousarray(rc[:length // b][::-1])
+    rem_commitment = h.hash_elements(remainder.reshape(-1))
+    coin.reseed(rem_commitment)
+    # 6. proof of work (serial rule: the smallest nonce >= 1) and query positions
+    pow_seed = coin.seed.copy()
+    nonce = 1
+    while coin.check_leading_zeros(nonce) < options.grinding_factor:
+        nonce += 1
+    positions = sorted(set(coin.draw_integers(options.num_queries, n * b, nonce)))
+    art.update(trace_root=trace_root, trace_polys=polys, constraint_coefficients=(cc_t, cc_b), constraint_root=constraint_root,
+               composition_poly=cpoly, ood_point=z, ood_trace_frame=(t_cur, t_next), ood_constraint_frame=(q_cur, q_next),
+               deep_coefficients=(dc_t, dc_c), fri_roots=fri_roots, fri_alphas=alphas, fri_remainder=remainder,
+               fri_remainder_commitment=rem_commitment, pow_seed=pow_seed, pow_nonce=nonce, query_positions=positions,
+               trace_lde=lde, constraint_lde=q_lde, num_composition_columns=ncols)
+    return art

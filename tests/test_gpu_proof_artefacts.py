@@ -1,0 +1,99 @@
+"""Reference-exact proof artefacts: the GPU pipeline (winterfell_amd.prover.prove: every data-parallel step on the device,
+the Fiat-Shamir channel on the host) against the CPU oracle's restatement of the whole of Prover::generate_proof
+(oracle/prover.py over the oracle's C restatements; prover/src/lib.rs:282-492, prover/src/channel.rs:57-185).
+
+Both sides seed the coin the way the reference does — hash_elements(Context::to_elements() ++ PublicInputs::to_elements())
+(air/src/proof/context.rs:106-137, air/src/air/trace_info.rs:209-238, air/src/options.rs:294-305,
+examples/src/rescue/air.rs:45-51) — and are written independently of each other, so equality of every artefact below is
+SURVEY D5's definition of a bit-exact proof: trace root, constraint composition coefficients, constraint root,
+out-of-domain point and frames, DEEP coefficients, every FRI layer root and folding challenge, the remainder polynomial and
+its commitment, the proof-of-work nonce (serial rule: the smallest one) and the query positions, plus the rows opened at
+those positions."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(oracle, example, fname, hname, n, D, num_queries=28, blowup=8, grinding=16, folding=4, rem_deg=31):
+    import winterfell_amd
+    from oracle import prover as oprover
+    from winterfell_amd import air as wair, crypto, prover
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    hasher = getattr(crypto, hname)
+    hid = {"Blake3_256": 0, "Rp64_256": 1}[hname]
+    fld, ofld = {"f64": (fields.f64, oracle.f64t), "f128": (fields.f128, oracle.f128)}[fname]
+    # ---- CPU: the oracle's whole prover
+    want = oprover.prove(example, ofld, hid, n, oprover.Options(num_queries, blowup, grinding, D, folding, rem_deg))
+    # ---- GPU: the product's prove() on the same trace, public inputs the way the example's PublicInputs::to_elements lists them
+    ex = oprover.example(example, ofld, n)
+    trace = ex["trace"]
+    if example == "fib_small":
+        air = wair.FibSmall(n, ex["pub"][0], blowup, fld)
+    else:
+        air = wair.RescueAir(n, ex["pub"][:2], ex["pub"][2:], blowup)
+    options = prover.ProofOptions(num_queries, blowup, grinding, ext_degree=D, fri_folding_factor=folding, fri_remainder_max_degree=rem_deg)
+    proof = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, ex["pub"])
+    return want, proof, fld, ctx
+
+
+def _check(want, proof, fld):
+    eq = np.array_equal
+    assert eq(proof.trace_commitment, want["trace_root"]), "trace root"
+    cc_t, cc_b = want["constraint_coefficients"]
+    assert eq(proof.constraint_coefficients.transition.reshape(cc_t.shape), cc_t) and eq(proof.constraint_coefficients.boundary.reshape(cc_b.shape), cc_b), \
+        "constraint composition coefficients"
+    assert eq(proof.constraint_commitment, want["constraint_root"]), "constraint root"
+    assert proof.num_composition_columns == want["num_composition_columns"]
+    assert eq(np.asarray(proof.ood_point).reshape(-1), want["ood_point"]), "out-of-domain point"
+    for got, exp, what in zip(proof.ood_trace_frame + proof.ood_constraint_frame, want["ood_trace_frame"] + want["ood_constraint_frame"],
+                              ("trace frame, current row", "trace frame, next row", "quotient frame, current row", "quotient frame, next row")):
+        assert eq(np.asarray(got).reshape(-1), exp.reshape(-1)), what
+    for got, exp in zip(proof.deep_coefficients, want["deep_coefficients"]):
+        assert eq(np.asarray(got).reshape(-1), exp.reshape(-1)), "DEEP composition coefficients"
+    # commitments = [trace root, constraint root, FRI layer roots ..., remainder commitment] (channel.rs:87-98, fri channel)
+    roots = proof.commitments[2:]
+    assert len(roots) == len(want["fri_roots"]) + 1
+    for k, (got, exp) in enumerate(zip(roots, want["fri_roots"] + [want["fri_remainder_commitment"]])):
+        assert eq(got, exp), "FRI commitment %d" % k
+    for k, (got, exp) in enumerate(zip(proof.fri_alphas, want["fri_alphas"])):
+        assert eq(np.asarray(got).reshape(-1), exp.reshape(-1)), "FRI alpha %d" % k
+    assert eq(np.asarray(proof.fri_remainder).reshape(-1), want["fri_remainder"].reshape(-1)), "FRI remainder"
+    assert eq(proof.pow_seed, want["pow_seed"]) and proof.pow_nonce == want["pow_nonce"], "proof-of-work nonce"
+    assert list(proof.query_positions) == want["query_positions"], "query positions"
+    # the opened rows are the oracle's LDE rows at those positions
+    (t_rows, _), = proof.trace_queries
+    c_rows, _ = proof.constraint_queries
+    pos = want["query_positions"]
+    assert eq(np.asarray(t_rows), want["trace_lde"][pos][:, : np.asarray(t_rows).shape[1]]), "queried trace rows"
+    assert eq(np.asarray(c_rows), want["constraint_lde"][pos][:, : np.asarray(c_rows).shape[1]]), "queried constraint rows"
+
+
+@pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 1), ("fib_small", "f64", "Rp64_256", 1 << 8, 2),
+                                                      ("fib_small", "f64", "Blake3_256", 1 << 12, 3), ("rescue", "f128", "Blake3_256", 1 << 10, 2),
+                                                      ("rescue", "f128", "Blake3_256", 1 << 10, 1)])
+def test_proof_artefacts_equal_the_cpu_prover(oracle, example, fname, hname, n, D):
+    want, proof, fld, ctx = _run(oracle, example, fname, hname, n, D)
+    _check(want, proof, fld)
+
+
+def test_context_elements_follow_the_reference_encoding(oracle):
+    """Context::to_elements by hand for examples::rescue at 2^10 rows with the examples' default options (28 queries, blowup 8,
+    grinding 16, quadratic extension, folding 4, remainder degree 31): [width << 8 | aux segments, length, modulus low half,
+    modulus high half, constraints, ext << 24 | folding << 16 | remainder << 8 | blowup, grinding, queries]."""
+    from winterfell_amd import air as wair, prover
+    from winterfell_amd.prover.channel import context_to_elements
+    air = wair.RescueAir(1 << 10, [1, 2], [3, 4], 8)
+    opts = prover.ProofOptions(28, 8, 16, ext_degree=2, fri_folding_factor=4, fri_remainder_max_degree=31)
+    m = 2**128 - 45 * 2**40 + 1
+    assert context_to_elements(air, opts) == [4 << 8, 1 << 10, m & (2**64 - 1), m >> 64, 8, (2 << 24) | (4 << 16) | (31 << 8) | 8, 16, 28]
+    from oracle import prover as oprover
+    assert oprover.context_to_elements(m, 16, 4, 1 << 10, 8, oprover.Options(28, 8, 16, 2, 4, 31)) == context_to_elements(air, opts)
+
+
+def test_rescue_example_at_full_size(oracle):
+    """BASELINE configs[2] / north_star: examples::rescue (f128, seed [42, 43], 2^16 hash chain -> 2^20 rows), blowup 8,
+    quadratic extension, Blake3_256, the examples' default options — every artefact of the proof equals the CPU prover's."""
+    want, proof, fld, ctx = _run(oracle, "rescue", "f128", "Blake3_256", 1 << 20, 2)
+    _check(want, proof, fld)

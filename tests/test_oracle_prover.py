@@ -1,0 +1,65 @@
+"""The oracle's whole-prover restatement (oracle/prover.py) on the CPU: the reference's transcript encoding by hand, and the
+artefacts it produces checked with what a VERIFIER computes from them (verifier/src/lib.rs:139-330, evaluator.rs:16-89) —
+the out-of-domain constraint equation at the drawn point, proof of work, the query-position rule — so that the checker the
+GPU pipeline is compared with (tests/test_gpu_proof_artefacts.py) is itself pinned."""
+import numpy as np
+import pytest
+
+from verifier_util import Ext, ood_constraint_equation_holds
+
+
+def test_context_and_options_encoding(oracle):
+    from oracle import prover as op
+    o = op.Options(28, 8, 16, 2, 4, 31)
+    assert o.to_elements() == [(2 << 24) | (4 << 16) | (31 << 8) | 8, 16, 28]                      # air/src/options.rs:294-305
+    assert op.trace_info_to_elements(4, 1 << 20, 16) == [4 << 8, 1 << 20]                          # no aux segment, no metadata
+    assert op.trace_info_to_elements(3, 64, 8, aux_width=2, num_aux_rands=5) == [(((3 << 8 | 1) << 8 | 2) << 8) | 5, 64]
+    assert op.trace_info_to_elements(1, 8, 8, meta=bytes(range(1, 10))) == [1 << 8, 8, int.from_bytes(bytes(range(1, 8)), "little"), 8 | 9 << 8]
+    m64 = 2**64 - 2**32 + 1
+    # fib_small at 2^16 rows: 3 assertions + 2 transition constraints; modulus bytes 01 00 00 00 | ff ff ff ff
+    assert op.context_to_elements(m64, 8, 2, 1 << 16, 5, op.Options(28, 8, 16, 1, 8, 127)) == \
+        [2 << 8, 1 << 16, 1, 0xFFFFFFFF, 5, (1 << 24) | (8 << 16) | (127 << 8) | 8, 16, 28]
+
+
+@pytest.mark.parametrize("name,fname,hid,n,D", [("fib_small", "f64t", 0, 64, 1), ("fib_small", "f64t", 1, 32, 2), ("rescue", "f128", 0, 64, 2),
+                                               ("rescue", "f128", 0, 128, 1)])
+def test_cpu_prover_artefacts_satisfy_the_verifiers_checks(oracle, name, fname, hid, n, D):
+    from oracle import prover as op
+    fld = getattr(oracle, fname)
+    opts = op.Options(16, 8, 5, D, 4, 7)
+    art = op.prove(name, fld, hid, n, opts)
+    again = op.prove(name, fld, hid, n, opts)
+    assert np.array_equal(art["trace_root"], again["trace_root"]) and art["query_positions"] == again["query_positions"]   # deterministic
+    # proof of work: the nonce qualifies and no smaller one does (serial `find`, prover/src/channel.rs:171-175)
+    h = op.Hasher(hid, fld)
+    coin = op.Coin.__new__(op.Coin)
+    coin.h, coin.seed, coin.counter = h, art["pow_seed"], 0
+    assert coin.check_leading_zeros(art["pow_nonce"]) >= opts.grinding_factor
+    assert all(coin.check_leading_zeros(k) < opts.grinding_factor for k in range(1, art["pow_nonce"]))
+    pos = art["query_positions"]
+    assert pos == sorted(set(pos)) and 0 < len(pos) <= opts.num_queries and max(pos) < n * opts.blowup_factor
+    # the verifier's out-of-domain consistency equation at z with the drawn coefficients
+    ex = op.example(name, fld, n)
+    one = op.to_internal(fld, 1)
+    E = Ext(fld, D, one)
+    z = fld.unpack(art["ood_point"])
+    t_cur, t_next = art["ood_trace_frame"]
+    q_cur, _ = art["ood_constraint_frame"]
+    zn = E.pow(z, n)
+    H, zi = [0] * D, E.lift(one)
+    for i in range(art["num_composition_columns"]):
+        H = E.add(H, E.mul(zi, fld.unpack(q_cur[i])))
+        zi = E.mul(zi, zn)
+    per = np.zeros(0, dtype=np.uint64)
+    if name == "rescue":
+        per = fld.evaluate_columns_at(fld.air_periodic_polys(1), 9, fld.pack(E.pow(z, n // 16)), D, 1).reshape(-1)
+    nt = len(ex["degrees"])
+    tev = fld.unpack(fld.air_evaluate_transition(ex["air"], D, t_cur.reshape(-1), t_next.reshape(-1), per))
+    cc_t, cc_b = art["constraint_coefficients"]
+    assertions = sorted(ex["assertions"], key=lambda a: (0, a[1], a[0]))
+    g = fld.root_of_unity(n.bit_length() - 1)
+    assert ood_constraint_equation_holds(E, one, g, n, z, H, [tev[k * D:(k + 1) * D] for k in range(nt)], [fld.unpack(c) for c in cc_t],
+                                         [fld.unpack(r) for r in t_cur], assertions, [fld.unpack(c) for c in cc_b], num_exemptions=ex["exemptions"])
+    # the remainder has len/blowup coefficients and commits to them
+    rem = art["fri_remainder"]
+    assert np.array_equal(h.hash_elements(rem.reshape(-1)), art["fri_remainder_commitment"])

@@ -1,9 +1,11 @@
 """ProverChannel (prover/src/channel.rs:17-215): the prover's side of the Fiat-Shamir transcript.
 
 Host logic around a DefaultRandomCoin; the one data-parallel step, grind_query_seed, runs on the GPU.  The coin is seeded
-with the public inputs and the proof parameters; the byte-level serialisation of the reference's `Context` is not
-reproduced (proof objects are out of scope), so transcripts produced here are self-consistent but not
-byte-compatible with the Rust prover's."""
+exactly like the reference's: hash_elements(Context::to_elements() ++ PublicInputs::to_elements()) (channel.rs:57-75) with
+the reference's encodings of TraceInfo, the field modulus, the constraint count and ProofOptions, so every value drawn from
+it — and therefore every commitment, out-of-domain frame, FRI layer, nonce and query position of prove() — is the one the
+Rust prover produces for the same trace and options (tests/test_gpu_proof_artefacts.py compares them with the CPU oracle's
+restatement of the whole prover)."""
 import numpy as np
 
 from ..crypto.random import DefaultRandomCoin, grind_query_seed
@@ -19,14 +21,45 @@ class ProofOptions:
         self.ext_degree, self.fri_folding_factor, self.fri_remainder_max_degree = ext_degree, fri_folding_factor, fri_remainder_max_degree
 
 
+def trace_info_to_elements(main_width, trace_length, element_bytes, aux_width=0, num_aux_rands=0, meta=b""):
+    """TraceInfo::to_elements (air/src/air/trace_info.rs:209-238), canonical integers: segment widths packed 8 bits each
+    into one element, the trace length, then the metadata in chunks of ELEMENT_BYTES - 1 bytes."""
+    num_aux_segments = 1 if aux_width else 0
+    buf = (main_width << 8) | num_aux_segments
+    if num_aux_segments:
+        buf = (((buf << 8) | aux_width) << 8) | num_aux_rands
+    out = [buf, trace_length & 0xFFFFFFFF]
+    step = element_bytes - 1
+    return out + [int.from_bytes(meta[i:i + step], "little") for i in range(0, len(meta), step)]
+
+
+def proof_options_to_elements(options):
+    """ProofOptions::to_elements (air/src/options.rs:294-305): FieldExtension discriminants are None = 1, Quadratic = 2,
+    Cubic = 3, i.e. the extension degree."""
+    buf = (((((options.ext_degree << 8) | options.fri_folding_factor) << 8) | options.fri_remainder_max_degree) << 8) | options.blowup_factor
+    return [buf, options.grinding_factor, options.num_queries]
+
+
+def context_to_elements(air, options, aux_width=0, num_aux_rands=0, meta=b""):
+    """Context::to_elements (air/src/proof/context.rs:106-137) for a built-in AIR, as canonical integers: trace info, the
+    field modulus' little-endian bytes split into two elements, the number of constraints, the proof options."""
+    f = air.FIELD
+    nbytes = 8 * f.W
+    out = trace_info_to_elements(air.TRACE_WIDTH, air.trace_length(), nbytes, aux_width, num_aux_rands, meta)
+    mb = f.M.to_bytes(nbytes, "little")
+    out += [int.from_bytes(mb[:nbytes // 2], "little"), int.from_bytes(mb[nbytes // 2:], "little")]
+    out.append((air.num_assertions() + air.num_transition_constraints()) & 0xFFFFFFFF)
+    return out + proof_options_to_elements(options)
+
+
 class ProverChannel:
     def __init__(self, air, options: ProofOptions, hasher, pub_inputs_elements, ctx=None):
+        """pub_inputs_elements: PublicInputs::to_elements() of the AIR in the field's internal representation (rescue:
+        seed ++ result, examples/src/rescue/air.rs:45-51; the Fibonacci examples: the result; vdf: [seed, result])."""
         f = air.FIELD
         self.air, self.options, self.hasher, self.ctx = air, options, hasher, ctx
-        context = [air.TRACE_WIDTH, air.trace_length(), options.blowup_factor, options.num_queries, options.grinding_factor,
-                   options.ext_degree, options.fri_folding_factor, options.fri_remainder_max_degree,
-                   air.num_assertions() + air.num_transition_constraints()]
-        seed = f.pack([f.new(v) for v in context] + list(pub_inputs_elements))
+        self.context_elements = context_to_elements(air, options)
+        seed = f.pack([f.new(v) for v in self.context_elements] + list(pub_inputs_elements))
         self.public_coin = DefaultRandomCoin(hasher, f, seed, ctx)
         self.commitments, self.fri_alphas = [], []
         self.ood_frame = None
