@@ -1,4 +1,6 @@
 // Context, device memory helpers, scratch buffers and cached constant tables.
+#include <stdlib.h>
+
 #include "wf_internal.h"
 
 #include <stdio.h>
@@ -41,6 +43,7 @@ extern "C" int wf_ctx_create(int device_id, wf_ctx **out) {
         return WF_ERR_HIP;
     }
     ctx->own_stream = true;
+    if (const char *e = getenv("WF_NTT_PREFETCH")) ctx->ntt_prefetch = e[0] == '1';
     *out = ctx;
     return WF_OK;
 }
@@ -219,6 +222,21 @@ extern "C" int wf_prof_collect(wf_ctx *ctx, char *h_buf, size_t buf_len) {
         if (w < 0 || (size_t)w >= buf_len - off) break;
         off += (size_t)w;
     }
+    return WF_OK;
+}
+
+// ---- persistent launches -----------------------------------------------------------------------------
+// CUs x (256-thread workgroups of `kernel` the occupancy calculator admits per CU), cached per kernel.  The grid of a
+// persistent kernel: every workgroup is resident from the start and walks its share of the tiles.
+int wf_resident_blocks(wf_ctx *ctx, const void *kernel, uint32_t *out) {
+    auto it = ctx->resident_blocks.find(kernel);
+    if (it == ctx->resident_blocks.end()) {
+        int cus = 0, per_cu = 0;
+        WF_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device));
+        WF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 256, 0));
+        it = ctx->resident_blocks.emplace(kernel, (uint32_t)(cus > 0 && per_cu > 0 ? cus * per_cu : 0)).first;
+    }
+    *out = it->second;
     return WF_OK;
 }
 

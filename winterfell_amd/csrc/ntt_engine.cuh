@@ -92,9 +92,22 @@ __device__ __forceinline__ void divmod_uniform(uint32_t x, uint32_t d, uint32_t 
 
 // TWTAB (non-last passes): the inter-pass twiddles come from the pass's L2-resident table (p.tw_tab) instead of the per-lane
 // progression; a compile-time switch so that neither variant carries the other's registers
-template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB>
-__global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typename F::T> p) {
+//
+// PF (prefetch, an experiment kept behind WF_NTT_PREFETCH=1): the launch is a grid of persistent workgroups that walk the
+// tiles (tile = blockIdx.x, + gridDim.x, ...) and issue the NEXT tile's global loads right after the LDS exchange barrier, so
+// that they are in flight during step 2 (the second DFT, the inter-pass twiddles, the stores) instead of being waited for at
+// the top of a fresh workgroup: twice the bytes in flight per workgroup for 32 more VGPRs.  Measured result (round 2, 2^24
+// f64): 304 us per transform against 227 us for the plain launches — the extra registers cost a wave per SIMD (168-VGPR cap,
+// with spills in the last-pass kernel; at two waves and no spills: 333 us), and occupancy is worth more to this kernel than
+// memory-level parallelism.  The vm counter retires in order, so step 2 must not wait on loads ISSUED AFTER the prefetch: the
+// table kernel (32 table loads per lane in step 2) is never launched with PF.
+#ifndef NTT_PF_WAVES
+#define NTT_PF_WAVES 3     // waves per SIMD the prefetching variants are compiled for (<= 168 VGPRs)
+#endif
+template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF>
+__global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : 1))) void ntt_pass(PassParams<typename F::T> p) {
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
+    static_assert(!(PF && TWTAB), "the table kernel's step-2 loads would drain the prefetch (in-order vm counter)");
     typedef typename F::T T;
     constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
     constexpr int TC = 256 / B;         // tile columns
@@ -121,7 +134,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * TC * ROW_L : A * ROW_NL);
     __shared__ T lds[LDS_ELEMS];
 
-    const int tid = threadIdx.x;
+    int tid = threadIdx.x;
     const uint32_t L = p.log_n;
     const uint64_t n = 1ull << L;
     const uint64_t ncols = n >> LOG_R;                     // columns per vector
@@ -148,23 +161,27 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
         v = ((uint64_t)bc << p.rm_log_b) + u;
         return bc < p.rm_base_cols;
     };
-    const uint64_t cc0 = (uint64_t)blockIdx.x * TC;
-
     // log2 of this digit's stride S_p
-    uint32_t log_s = L;
-    for (uint32_t q = 0; q <= p.pass; q++) log_s -= p.log_r[q];
-    const uint32_t log_mult = L - log_s - LOG_R;           // n / n_p = R_1..R_{p-1}
+    uint32_t log_s0 = L;
+    for (uint32_t q = 0; q <= p.pass; q++) log_s0 -= p.log_r[q];
+    const uint32_t log_mult = L - log_s0 - LOG_R;          // n / n_p = R_1..R_{p-1}
+    // In the persistent (PF) variants the stride is re-read through an opaque move in every iteration: otherwise the compiler
+    // hoists the 2 x 16 per-register address offsets (and more) out of the tile loop and the kernel needs 250-330 VGPRs
+    auto opaque = [](uint32_t v) -> uint32_t {
+        if constexpr (PF) asm volatile("" : "+s"(v));
+        return v;
+    };
+    uint32_t log_s = log_s0;
 
-    // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
     int b1, t1;
     if (!LAST) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
-    T x[A];
-    {
-        const uint64_t cc = cc0 + t1;
-        uint64_t v = 0, c = 0;
+    // issue the loads of this lane's A inputs of tile `tile` (no wait); also returns what step 1 needs to know about them
+    auto load_inputs = [&](uint64_t tile, T (&xin)[A], bool &active, uint64_t &v, uint64_t &base) {
+        const uint64_t cc = tile * TC + t1;
+        uint64_t c = 0;
         uint32_t bc1, u1;
-        const bool active = cc < total_cols && decompose(cc, v, c, bc1, u1);
-        uint64_t base;
+        v = 0;
+        active = cc < total_cols && decompose(cc, v, c, bc1, u1);
         if (!LAST) {
             const uint64_t rem = c & ((1ull << log_s) - 1);
             base = ((c >> log_s) << (log_s + LOG_R)) + rem;
@@ -186,8 +203,32 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
 #pragma unroll
             for (int a = 0; a < A; a++) {
                 const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                x[a] = F::load_norm(src[j * p.src_es]);
+                xin[a] = F::load_norm(src[j * p.src_es]);
             }
+        } else {
+#pragma unroll
+            for (int a = 0; a < A; a++) xin[a] = F::zero();
+        }
+    };
+
+    const uint64_t ntiles = (total_cols + TC - 1) / TC;
+    uint64_t tile = blockIdx.x;
+    T x[A];
+    bool active;
+    uint64_t v1, base1;
+    load_inputs(tile, x, active, v1, base1);
+    for (;;) {
+    log_s = opaque(log_s0);
+    if constexpr (PF) {
+        // the same for everything derived from the lane index (LDS addresses, table addresses, b1 / t1 / t2 / q2)
+        asm volatile("" : "+v"(tid));
+        if (!LAST) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
+    }
+    const uint64_t cc0 = tile * TC;
+    // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
+    {
+        const uint64_t v = v1, base = base1;
+        if (active) {
             if (p.pre_lo != nullptr && p.pass == 0) {
                 uint32_t uq, u;
                 divmod_uniform((uint32_t)v, p.pre_mod, uq, u);
@@ -202,9 +243,6 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
                     if (a + 1 < A) cur = F::mul(cur, stp);
                 }
             }
-        } else {
-#pragma unroll
-            for (int a = 0; a < A; a++) x[a] = F::zero();
         }
         if constexpr (F::USE_L24) {
             // f64: the DFT runs on four 24-bit limbs per element (l24.cuh); leaving that representation IS the intra-pass
@@ -260,7 +298,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
     const int t2 = (B > 1) ? tid % TC : t1;
     const int q2 = (B > 1) ? tid / TC : 0;
     const uint64_t cc = cc0 + t2;
-    if (cc >= total_cols) return;
+    // the next tile's loads go out now: they stay in flight through the whole of step 2
+    const uint64_t next_tile = tile + gridDim.x;
+    const bool more = PF && next_tile < ntiles;
+    T xn[A];
+    bool active_n = false;
+    uint64_t vn = 0, basen = 0;
+    if (more) load_inputs(next_tile, xn, active_n, vn, basen);
+    if (cc < total_cols) {
     uint64_t v, c;
     uint32_t bc2, u2;
     const bool real_col = decompose(cc, v, c, bc2, u2);
@@ -394,28 +439,48 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR void ntt_pass(PassParams<typena
             }
         }
     }
+    }   // cc < total_cols
+    if (!more) break;
+    if (B > 1) __syncthreads();          // every lane is done reading the exchange buffer before the next tile overwrites it
+#pragma unroll
+    for (int a = 0; a < A; a++) x[a] = xn[a];
+    active = active_n;
+    v1 = vn;
+    base1 = basen;
+    tile = next_tile;
+    }   // tiles
 }
 
+// the prefetching (persistent) variants exist for the radices whose tiles are big enough to be latency bound, f64 only
 template <class F, int LA, int LB>
-auto pick(bool last, bool twtab) -> void (*)(PassParams<typename F::T>) {
+constexpr bool has_prefetch_variant() { return F::USE_L24 && LA + LB >= 6; }
+
+template <class F, int LA, int LB>
+auto pick(bool last, bool twtab, bool pf) -> void (*)(PassParams<typename F::T>) {
     typedef void (*fn)(PassParams<typename F::T>);
-    if (last) return (fn)ntt_pass<F, LA, LB, true, false>;
-    return twtab ? (fn)ntt_pass<F, LA, LB, false, true> : (fn)ntt_pass<F, LA, LB, false, false>;
+    if constexpr (has_prefetch_variant<F, LA, LB>()) {
+        if (pf && !twtab) return last ? (fn)ntt_pass<F, LA, LB, true, false, true> : (fn)ntt_pass<F, LA, LB, false, false, true>;
+    }
+    if (last) return (fn)ntt_pass<F, LA, LB, true, false, false>;
+    return twtab ? (fn)ntt_pass<F, LA, LB, false, true, false> : (fn)ntt_pass<F, LA, LB, false, false, false>;
 }
 
 template <class F>
-auto kernel_for(uint32_t r, bool last, bool twtab) -> void (*)(PassParams<typename F::T>) {
+auto kernel_for(uint32_t r, bool last, bool twtab, bool pf) -> void (*)(PassParams<typename F::T>) {
     switch (r) {
-        case 1: return pick<F, 1, 0>(last, twtab);
-        case 2: return pick<F, 1, 1>(last, twtab);
-        case 3: return pick<F, 2, 1>(last, twtab);
-        case 4: return pick<F, 2, 2>(last, twtab);
-        case 5: return pick<F, 3, 2>(last, twtab);
-        case 6: return pick<F, 3, 3>(last, twtab);
-        case 7: return pick<F, 4, 3>(last, twtab);
-        default: return pick<F, 4, 4>(last, twtab);
+        case 1: return pick<F, 1, 0>(last, twtab, pf);
+        case 2: return pick<F, 1, 1>(last, twtab, pf);
+        case 3: return pick<F, 2, 1>(last, twtab, pf);
+        case 4: return pick<F, 2, 2>(last, twtab, pf);
+        case 5: return pick<F, 3, 2>(last, twtab, pf);
+        case 6: return pick<F, 3, 3>(last, twtab, pf);
+        case 7: return pick<F, 4, 3>(last, twtab, pf);
+        default: return pick<F, 4, 4>(last, twtab, pf);
     }
 }
+
+template <class F>
+static bool prefetch_variant_exists(uint32_t r) { return F::USE_L24 && r >= 6; }
 
 inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
 
@@ -578,14 +643,6 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             p.w256 = (const T *)ws;
             p.scale_in_w256 = 1;
         }
-        p.tw_tab = nullptr;
-        if (!last) {
-            uint32_t log_s = L;
-            for (uint32_t qq = 0; qq <= q; qq++) log_s -= p.log_r[qq];
-            const void *tab;
-            WF_TRY(get_pass_twiddles<HF>(ctx, om, L, r, log_s, L - log_s - r, &tab));
-            p.tw_tab = (const T *)tab;
-        }
         const uint32_t Tc = 256u >> log_b_for(r);
         uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;
         p.rowmajor = (last && job.rowmajor) ? 1 : 0;
@@ -595,9 +652,27 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         }
         const uint64_t blocks = (total_cols + Tc - 1) / Tc;
         if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
-        auto k = kernel_for<F>(r, last, p.tw_tab != nullptr);
+        // Persistent prefetching launch (see ntt_pass): whole tiles only, and enough of them that every resident workgroup gets
+        // several — otherwise one workgroup per tile as before.  Such a pass takes its inter-pass twiddles from the per-lane
+        // progression, never from the table (whose loads in step 2 would drain the prefetch).
+        uint32_t resident = 0;
+        bool pf = false;
+        if (ctx->ntt_prefetch && prefetch_variant_exists<F>(r) && total_cols % Tc == 0) {
+            auto kp = kernel_for<F>(r, last, false, true);
+            WF_TRY(wf_resident_blocks(ctx, (const void *)kp, &resident));
+            pf = resident > 0 && blocks >= 4ull * resident;
+        }
+        p.tw_tab = nullptr;
+        if (!last && !pf) {
+            uint32_t log_s = L;
+            for (uint32_t qq = 0; qq <= q; qq++) log_s -= p.log_r[qq];
+            const void *tab;
+            WF_TRY(get_pass_twiddles<HF>(ctx, om, L, r, log_s, L - log_s - r, &tab));
+            p.tw_tab = (const T *)tab;
+        }
+        auto k = kernel_for<F>(r, last, p.tw_tab != nullptr, pf);
         wf_prof_begin(ctx, last ? "ntt_pass_last" : "ntt_pass");
-        hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
+        hipLaunchKernelGGL(k, dim3(pf ? resident : (uint32_t)blocks), dim3(256), 0, ctx->stream, p);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
     }

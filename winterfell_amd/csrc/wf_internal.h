@@ -76,6 +76,12 @@ struct wf_ctx {
     std::map<void *, size_t> pool_live;            // block -> its (rounded) size
     size_t pool_free_bytes = 0;
 
+    // persistent launches: how many workgroups of a kernel the device keeps resident (CUs x occupancy), per kernel
+    std::map<const void *, uint32_t> resident_blocks;
+    // WF_NTT_PREFETCH=1 switches the persistent, next-tile-prefetching NTT launches on.  Off by default: measured slower on
+    // MI355X (2^24 f64: 304 us vs 227 us; the 32 extra VGPRs cost a wave per SIMD)
+    bool ntt_prefetch = false;
+
     // scratch buffers (grow-only)
     void *scratch[3] = {nullptr, nullptr, nullptr};
     size_t scratch_bytes[3] = {0, 0, 0};
@@ -83,6 +89,7 @@ struct wf_ctx {
 };
 
 int wf_scratch(wf_ctx *ctx, int slot, size_t bytes, void **out);
+int wf_resident_blocks(wf_ctx *ctx, const void *kernel, uint32_t *out);   // 256-thread workgroups resident on the whole device
 
 // RAII-less helpers: bracket a kernel launch with events when profiling is on
 inline void wf_prof_begin(wf_ctx *ctx, const char *name) {
