@@ -299,6 +299,42 @@ int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree, const voi
                           uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
                           const void *h_alpha, void *d_folded);
 
+/* ---- multi-device: one rank per GPU (SURVEY 8b `device_ids[]`, 8e) ------------------------------------------- */
+/* The reference's multi-device hook is PartitionOptions (air/src/options.rs:391-451): with num_partitions = G every device
+ * owns one partition's columns, hashes its part of every row (row_matrix.rs:204-223), and a row's leaf is merge_many over
+ * the G partition digests.  A wf_comm ties one context (= one GPU) to its peers; the two exchange steps of the commitment
+ * run on the device interconnect (RCCL over xGMI: all-to-all of the 32-byte partition digests, all-gather of the G
+ * sub-roots).  One process per GPU is the intended deployment: rank 0 calls wf_comm_get_unique_id and hands the 128 bytes
+ * to the other ranks (the Rust host already has a channel for that), every rank calls wf_comm_init_rank.  Ranks that are
+ * threads of one process can use wf_comm_init_loopback instead (peer copies between the ranks' buffers, no RCCL): the
+ * single-process multi-GPU case and the way G logical ranks are tested on one GPU.  Collectives must be entered by every
+ * rank, in the same order. */
+#define WF_COMM_ID_BYTES 128
+typedef struct wf_comm wf_comm;
+int wf_comm_get_unique_id(uint8_t *id /* WF_COMM_ID_BYTES */);
+int wf_comm_init_rank(wf_ctx *ctx, const uint8_t *id, int rank, int world, wf_comm **out);
+int wf_comm_init_loopback(wf_ctx *const *ctxs, int world, wf_comm **out /* world handles, one per context */);
+int wf_comm_destroy(wf_comm *comm);
+int wf_comm_rank(const wf_comm *comm);
+int wf_comm_size(const wf_comm *comm);
+/* every rank contributes `bytes` bytes; d_recv receives world * bytes in rank order (sub-roots, FRI tails, remainders) */
+int wf_comm_all_gather(wf_comm *comm, const void *d_send, void *d_recv, uint64_t bytes);
+/* block k of d_send (`bytes` bytes each) goes to rank k, block k of d_recv comes from rank k; distinct buffers (partition
+ * digests, the FRI re-stride of fri/src/prover/mod.rs:202-211 over row-range shards) */
+int wf_comm_all_to_all(wf_comm *comm, const void *d_send, void *d_recv, uint64_t bytes);
+/* DefaultTraceLde::new / build_trace_commitment (prover/src/trace/trace_lde/default/mod.rs:63-86,245-282) with the columns
+ * sharded by partition: this rank holds partition `rank` (shard_cols columns of 2^log_n evaluations, col_stride words
+ * apart).  It interpolates and extends its columns, hashes its part of every LDE row, receives the other partitions'
+ * digests of ITS row range [rank N/G, (rank+1) N/G), N = 2^(log_n + log_blowup), merges them into leaves, builds the
+ * subtree over them, and after the sub-root all-gather the top log2 G levels.  On return (all device memory of this rank):
+ * d_trace_shard = polynomials, d_lde_shard = the shard's RowMatrix [N][wf_row_width(shard_cols, ext_degree)],
+ * d_leaves / d_nodes = N/G digests each (nodes in heap order), d_top = G digests, heap order, d_top[1] = the root (G = 1:
+ * d_top[0] = the root).  Node for node this is the single-device commitment under PartitionOptions::new(G, hash_rate) when
+ * shard_cols is that option's partition size; G must be a power of two. */
+int wf_comm_sharded_commit(wf_comm *comm, int hash, int field, uint32_t ext_degree, void *d_trace_shard, uint32_t shard_cols,
+                           uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, int skip_interpolate,
+                           void *d_lde_shard, void *d_leaves, void *d_nodes, void *d_top, void *h_root);
+
 #ifdef __cplusplus
 }
 #endif

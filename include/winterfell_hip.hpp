@@ -385,6 +385,76 @@ inline TraceCommitment build_trace_commitment(Hash h, const ColMatrix &trace, ui
     return TraceCommitment{std::move(lde), MerkleTree(h, std::move(leaves), std::move(nodes), trace.num_rows * blowup), std::move(polys)};
 }
 
+// ---- multi-device: one rank per GPU (wf_comm_*) -------------------------------------------------------------------------------
+// Comm: this rank's handle on the device interconnect.  Comm::rccl(ctx, id, rank, world) for one process (or thread) per GPU —
+// rank 0 creates the 128-byte id with Comm::unique_id() and the host distributes it; Comm::loopback(contexts) for ranks that
+// are threads of one process (no RCCL; also G logical ranks on one GPU).  sharded_commit is DefaultTraceLde::new with the
+// columns sharded by partition (PartitionOptions::new(G, .), air/src/options.rs:391-451): the partition digests cross the
+// interconnect in an all-to-all, the G sub-roots in an all-gather, everything else is local.
+struct ShardedCommitment {
+    RowMatrix lde;                  // this rank's columns over the whole LDE domain
+    DeviceBuffer leaves, nodes;     // this rank's row range: N / G leaves, and the subtree over them (heap order)
+    DeviceBuffer top;               // the top log2 G levels (G digests, heap order), identical on every rank
+    ColMatrix polys;
+    std::vector<uint8_t> root;
+};
+
+class Comm {
+public:
+    static std::vector<uint8_t> unique_id() {
+        std::vector<uint8_t> id(WF_COMM_ID_BYTES);
+        check(wf_comm_get_unique_id(id.data()), "wf_comm_get_unique_id");
+        return id;
+    }
+    static Comm rccl(Context &ctx, const std::vector<uint8_t> &id, int rank, int world) {
+        wf_comm *c = nullptr;
+        check(wf_comm_init_rank(ctx.handle(), id.data(), rank, world, &c), "wf_comm_init_rank");
+        return Comm(c, &ctx);
+    }
+    static std::vector<Comm> loopback(const std::vector<Context *> &ctxs) {
+        std::vector<wf_ctx *> h;
+        for (Context *c : ctxs) h.push_back(c->handle());
+        std::vector<wf_comm *> out(ctxs.size());
+        check(wf_comm_init_loopback(h.data(), (int)h.size(), out.data()), "wf_comm_init_loopback");
+        std::vector<Comm> r;
+        for (size_t i = 0; i < out.size(); i++) r.emplace_back(Comm(out[i], ctxs[i]));
+        return r;
+    }
+    Comm(Comm &&o) noexcept : c_(o.c_), ctx_(o.ctx_) { o.c_ = nullptr; }
+    Comm(const Comm &) = delete;
+    ~Comm() {
+        if (c_) wf_comm_destroy(c_);
+    }
+    int rank() const { return wf_comm_rank(c_); }
+    int size() const { return wf_comm_size(c_); }
+    void all_gather(const void *d_send, void *d_recv, uint64_t bytes) { check(wf_comm_all_gather(c_, d_send, d_recv, bytes), "wf_comm_all_gather"); }
+    void all_to_all(const void *d_send, void *d_recv, uint64_t bytes) { check(wf_comm_all_to_all(c_, d_send, d_recv, bytes), "wf_comm_all_to_all"); }
+
+    // `shard`: this rank's partition of the trace columns (evaluations over the trace domain)
+    ShardedCommitment sharded_commit(Hash h, const ColMatrix &shard, uint64_t blowup, const uint64_t *domain_offset) {
+        Context &ctx = *ctx_;
+        const uint64_t N = shard.num_rows * blowup, per = N / (uint64_t)size();
+        ShardedCommitment r{RowMatrix{}, DeviceBuffer(ctx, per * 32), DeviceBuffer(ctx, per * 32), DeviceBuffer(ctx, (size_t)size() * 32),
+                            ColMatrix{shard.data.clone(), shard.field, shard.num_cols, shard.ext_degree, shard.num_rows}, std::vector<uint8_t>(32)};
+        r.lde.field = shard.field;
+        r.lde.ext_degree = shard.ext_degree;
+        r.lde.num_rows = N;
+        r.lde.elements_per_row = shard.num_cols * shard.ext_degree;
+        r.lde.row_width = wf_row_width(shard.num_cols, shard.ext_degree);
+        r.lde.data = DeviceBuffer(ctx, N * r.lde.row_width * 8 * words(shard.field));
+        check(wf_comm_sharded_commit(c_, (int)h, (int)shard.field, shard.ext_degree, r.polys.data.data(), shard.num_cols, shard.col_stride(),
+                                     log2_exact(shard.num_rows, "rows"), log2_exact(blowup, "blowup factor"), domain_offset, 0, r.lde.data.data(),
+                                     r.leaves.data(), r.nodes.data(), r.top.data(), r.root.data()),
+              "wf_comm_sharded_commit");
+        return r;
+    }
+
+private:
+    Comm(wf_comm *c, Context *ctx) : c_(c), ctx_(ctx) {}
+    wf_comm *c_;
+    Context *ctx_;
+};
+
 // ---- fri::FriProver (commit phase) -------------------------------------------------------------------------------------------
 // Context::to_elements (air/src/proof/context.rs:106-137) as canonical integers — what the prover channel seeds its coin with,
 // followed by PublicInputs::to_elements() (prover/src/channel.rs:57-75).  TraceInfo::to_elements (air/src/air/trace_info.rs:209-238):

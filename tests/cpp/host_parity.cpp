@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <thread>
 #include <vector>
 
 #include "../../include/winterfell_hip.hpp"
@@ -134,6 +136,45 @@ int main() {
             ok = ok && y.to_host<uint64_t>() == want;
         }
         EXPECT(ok, "buffers recycled without synchronisation keep their contents (stream order)");
+    }
+
+    // ---- wf::Comm: the column-sharded commitment, 4 ranks as threads over the loopback transport, vs the oracle's partitioned one ----
+    {
+        const int G = 4;
+        const uint64_t n = 1 << 7, cps = 3, c = G * cps, blowup = 8, N = n * blowup, per = N / G;
+        std::vector<uint64_t> trace = rand_vec(c * n), o_trace = trace;
+        const uint64_t rw = or_row_width(c);
+        std::vector<uint64_t> o_lde(N * rw);
+        std::vector<uint8_t> o_leaves(N * 32), o_nodes(N * 32);
+        or_f64t_build_trace_commitment(0, o_trace.data(), c, n, 1, blowup, &offset, G, 1, o_lde.data(), o_leaves.data(), o_nodes.data());
+        std::vector<std::unique_ptr<wf::Context>> rctx;
+        std::vector<wf::Context *> rptr;
+        for (int r = 0; r < G; r++) {
+            rctx.emplace_back(new wf::Context(0));
+            rptr.push_back(rctx.back().get());
+        }
+        std::vector<wf::Comm> comms = wf::Comm::loopback(rptr);
+        std::vector<int> ok(G, 0);
+        std::vector<std::thread> th;
+        for (int r = 0; r < G; r++)
+            th.emplace_back([&, r]() {
+                std::vector<uint64_t> sh(trace.begin() + r * cps * n, trace.begin() + (r + 1) * cps * n);
+                wf::ColMatrix cm{wf::DeviceBuffer(*rptr[r], sh), F, (uint32_t)cps, 1, n};
+                wf::ShardedCommitment sc = comms[r].sharded_commit(wf::Hash::Blake3_256, cm, blowup, &offset);
+                const std::vector<uint8_t> leaves = sc.leaves.to_host<uint8_t>(), nodes = sc.nodes.to_host<uint8_t>(), top = sc.top.to_host<uint8_t>();
+                bool good = std::memcmp(leaves.data(), &o_leaves[r * per * 32], per * 32) == 0 && std::memcmp(sc.root.data(), &o_nodes[32], 32) == 0 &&
+                            std::memcmp(&top[32], &o_nodes[32], (G - 1) * 32) == 0;
+                for (uint64_t j = 1; j < per && good; j++) {      // local heap index j -> global ((G + r) << depth) + offset in level
+                    uint32_t depth = 0;
+                    while ((2ull << depth) <= j) depth++;
+                    good = std::memcmp(&nodes[j * 32], &o_nodes[((((uint64_t)G + r) << depth) + (j - (1ull << depth))) * 32], 32) == 0;
+                }
+                ok[r] = good;
+            });
+        for (auto &t : th) t.join();
+        bool all = true;
+        for (int r = 0; r < G; r++) all = all && ok[r];
+        EXPECT(all, "wf::Comm::sharded_commit over 4 loopback ranks == PartitionOptions(4, 1) commitment (leaves, subtrees, top tree, root)");
     }
 
     // ---- build_trace_commitment + MerkleTree (Blake3_256 and Rp64_256, partitions) ---------------------------------------------

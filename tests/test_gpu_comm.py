@@ -1,0 +1,181 @@
+"""The multi-device entry points of the C ABI (include/winterfell_hip.h: wf_comm_*): the column / partition sharded trace
+commitment with its two exchange steps, driven rank for rank through the library itself.
+
+Only one GPU is reachable here, so (a) the G-rank path runs over the LOOPBACK transport — G contexts on the one device, one
+thread per rank, the collectives as peer copies around a thread barrier — and is compared node for node with the
+single-device commitment under PartitionOptions::new(G, .) (air/src/options.rs:391-451, row_matrix.rs:204-223) and with the
+CPU oracle; (b) the RCCL transport is executed for real with a communicator of one rank (ncclCommInitRank, ncclAllGather,
+ncclAllToAll on the library's own dlopen()ed librccl)."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    return winterfell_amd.default_context(), crypto, prover, fields
+
+
+def _vp(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _sharded_commit(ctx0, comms, ctxs, hasher, fld, shards, log_n, log_b, offset_words, D=1):
+    """one thread per rank -> list of dict(polys, lde, leaves, nodes, top, root) as numpy"""
+    import torch
+    G, n, N = len(comms), 1 << log_n, 1 << (log_n + log_b)
+    per = N // G
+    out, errs = [None] * G, []
+    bufs = []
+    for r in range(G):                       # allocate on the main thread (torch), compute on the rank threads (library)
+        c = shards[r].shape[0]
+        rw = int(ctx0.lib.wf_row_width(c, D))
+        bufs.append(dict(tr=ctx0.to_device(shards[r]), lde=ctx0.empty_u64(N, rw * fld.W), leaves=ctx0.empty_u8(per, 32),
+                         nodes=ctx0.empty_u8(per, 32), top=ctx0.empty_u8(G, 32), root=np.zeros(32, dtype=np.uint8), c=c))
+    torch.cuda.synchronize()
+
+    def run(r):
+        try:
+            lib, b = ctx0.lib, bufs[r]
+            st = lib.wf_comm_sharded_commit(comms[r], hasher.HASH_ID, fld.ID, D, _vp(b["tr"]), b["c"], n * D * fld.W, log_n, log_b,
+                                            offset_words.ctypes.data_as(ctypes.c_void_p), 0, _vp(b["lde"]), _vp(b["leaves"]), _vp(b["nodes"]),
+                                            _vp(b["top"]), b["root"].ctypes.data_as(ctypes.c_void_p))
+            assert st == 0, "wf_comm_sharded_commit -> %d" % st
+            assert lib.wf_ctx_sync(ctxs[r]) == 0
+        except BaseException as e:        # noqa: BLE001 - reported by the main thread
+            errs.append(e)
+
+    ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not errs, errs
+    for r in range(G):
+        b = bufs[r]
+        out[r] = dict(polys=ctx0.to_host(b["tr"]), lde=ctx0.to_host(b["lde"]), leaves=ctx0.to_host(b["leaves"]), nodes=ctx0.to_host(b["nodes"]),
+                      top=ctx0.to_host(b["top"]), root=b["root"])
+    return out
+
+
+def _make_loopback(ctx0, G):
+    lib = ctx0.lib
+    handles = []
+    for _ in range(G):
+        h = ctypes.c_void_p()
+        assert lib.wf_ctx_create(ctx0.device.index or 0, ctypes.byref(h)) == 0
+        handles.append(h)
+    arr = (ctypes.c_void_p * G)(*[h.value for h in handles])
+    comms = (ctypes.c_void_p * G)()
+    assert lib.wf_comm_init_loopback(arr, G, comms) == 0
+    return handles, [ctypes.c_void_p(c) for c in comms]
+
+
+def _teardown(ctx0, handles, comms):
+    for c in comms:
+        ctx0.lib.wf_comm_destroy(c)
+    for h in handles:
+        ctx0.lib.wf_ctx_destroy(h)
+
+
+@pytest.mark.parametrize("hname,G,cols_per_shard,log_n,log_b", [("Blake3_256", 2, 3, 8, 3), ("Blake3_256", 4, 2, 7, 3), ("Rp64_256", 2, 2, 6, 2),
+                                                                 ("Blake3_256", 8, 1, 10, 3), ("Blake3_256", 4, 9, 6, 1)])
+def test_sharded_commit_over_loopback_equals_the_partitioned_commitment(wf, oracle, hname, G, cols_per_shard, log_n, log_b):
+    ctx, crypto, prover, fields = wf
+    f = fields.f64
+    hasher = getattr(crypto, hname)
+    n, c = 1 << log_n, G * cols_per_shard
+    trace = oracle.f64_from_int(rand_field(900 + G * 10 + c, n * c)).reshape(c, n)
+    shards = [trace[r * cols_per_shard:(r + 1) * cols_per_shard] for r in range(G)]
+    handles, comms = _make_loopback(ctx, G)
+    try:
+        assert [ctx.lib.wf_comm_rank(cm) for cm in comms] == list(range(G)) and ctx.lib.wf_comm_size(comms[0]) == G
+        res = _sharded_commit(ctx, comms, handles, hasher, f, shards, log_n, log_b, f.element_words(f.new(7)))
+    finally:
+        _teardown(ctx, handles, comms)
+    # the single-device commitment under PartitionOptions(G, 1): partition size = ceil(c / G) = cols_per_shard
+    hid = {"Blake3_256": 0, "Rp64_256": 1}[hname]
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(hid, trace, 1 << log_b, f.new(7), num_partitions=G, hash_rate=1)
+    N = n << log_b
+    per = N // G
+    for r in range(G):
+        assert np.array_equal(res[r]["polys"], o_polys[r * cols_per_shard:(r + 1) * cols_per_shard]), "polys of rank %d" % r
+        assert np.array_equal(res[r]["lde"][:, :cols_per_shard], o_lde[:, r * cols_per_shard:(r + 1) * cols_per_shard]), "LDE of rank %d" % r
+        assert np.array_equal(res[r]["leaves"], o_leaves[r * per:(r + 1) * per]), "leaves of rank %d" % r
+        assert np.array_equal(res[r]["root"], o_nodes[1]) and np.array_equal(res[r]["top"][1:], o_nodes[1:G]), "top tree on rank %d" % r
+        # the rank's subtree: local heap index j sits at global index ((G + r) << depth) + offset
+        for j in range(1, per):
+            depth = j.bit_length() - 1
+            assert np.array_equal(res[r]["nodes"][j], o_nodes[((G + r) << depth) + (j - (1 << depth))]), (r, j)
+    # ... which is also what the library's single-device entry point produces
+    lde, tree, _ = prover.build_trace_commitment(hasher, prover.ColMatrix(trace), prover.StarkDomain(n, 1 << log_b), prover.PartitionOptions(G, 1))
+    assert np.array_equal(tree.nodes, o_nodes)
+
+
+def test_collectives_over_loopback(wf):
+    ctx, crypto, prover, fields = wf
+    import torch
+    G, nbytes = 4, 96
+    handles, comms = _make_loopback(ctx, G)
+    try:
+        send = [ctx.to_device(np.full(G * nbytes, 10 * r, dtype=np.uint8) + np.repeat(np.arange(G, dtype=np.uint8), nbytes)) for r in range(G)]
+        recv_a2a = [ctx.empty_u8(G * nbytes) for _ in range(G)]
+        recv_ag = [ctx.empty_u8(G * nbytes) for _ in range(G)]
+        torch.cuda.synchronize()
+        errs = []
+
+        def run(r):
+            try:
+                assert ctx.lib.wf_comm_all_to_all(comms[r], _vp(send[r]), _vp(recv_a2a[r]), nbytes) == 0
+                assert ctx.lib.wf_comm_all_gather(comms[r], _vp(send[r]), _vp(recv_ag[r]), nbytes) == 0
+                assert ctx.lib.wf_ctx_sync(handles[r]) == 0
+            except BaseException as e:    # noqa: BLE001
+                errs.append(e)
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+        [t.start() for t in ts]
+        [t.join(timeout=120) for t in ts]
+        assert not errs, errs
+        for r in range(G):
+            a2a, ag = ctx.to_host(recv_a2a[r]).reshape(G, nbytes), ctx.to_host(recv_ag[r]).reshape(G, nbytes)
+            for k in range(G):
+                assert (a2a[k] == 10 * k + r).all()          # block r of rank k's send buffer
+                assert (ag[k] == 10 * k).all()               # block 0 of rank k's send buffer
+    finally:
+        _teardown(ctx, handles, comms)
+
+
+def test_rccl_transport_with_one_rank(wf, oracle):
+    """ncclGetUniqueId / ncclCommInitRank / ncclAllGather / ncclAllToAll actually execute (a communicator of ONE rank is all a
+    one-GPU box allows), and the sharded entry point over it equals the plain commitment (G = 1: the leaf is the row hash)."""
+    ctx, crypto, prover, fields = wf
+    import torch
+    f = fields.f64
+    uid = (ctypes.c_uint8 * 128)()
+    st = ctx.lib.wf_comm_get_unique_id(uid)
+    assert st == 0, "wf_comm_get_unique_id -> %d (librccl not loadable?)" % st
+    cm = ctypes.c_void_p()
+    assert ctx.lib.wf_comm_init_rank(ctx.handle, uid, 0, 1, ctypes.byref(cm)) == 0
+    try:
+        a = ctx.to_device(np.arange(256, dtype=np.uint8))
+        b, c = ctx.empty_u8(256), ctx.empty_u8(256)
+        torch.cuda.synchronize()
+        assert ctx.lib.wf_comm_all_gather(cm, _vp(a), _vp(b), 256) == 0 and ctx.lib.wf_comm_all_to_all(cm, _vp(a), _vp(c), 256) == 0
+        ctx.sync()
+        assert np.array_equal(ctx.to_host(b), np.arange(256, dtype=np.uint8)) and np.array_equal(ctx.to_host(c), np.arange(256, dtype=np.uint8))
+        n, cols, log_n, log_b = 512, 5, 9, 3
+        trace = oracle.f64_from_int(rand_field(4711, n * cols)).reshape(cols, n)
+        res = _sharded_commit(ctx, [cm], [ctx.handle], crypto.Blake3_256, f, [trace], log_n, log_b, f.element_words(f.new(7)))[0]
+        o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(0, trace, 8, f.new(7))
+        assert np.array_equal(res["polys"], o_polys) and np.array_equal(res["lde"], o_lde)
+        assert np.array_equal(res["leaves"], o_leaves) and np.array_equal(res["nodes"], o_nodes) and np.array_equal(res["root"], o_nodes[1])
+    finally:
+        ctx.lib.wf_comm_destroy(cm)

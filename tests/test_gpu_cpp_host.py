@@ -12,7 +12,7 @@ BIN = os.path.join(ROOT, "tests", "cpp", "host_parity.bin")
 
 def build():
     cmd = ["g++", "-O2", "-std=c++17", "-Wall", SRC, "-o", BIN, "-L" + os.path.join(ROOT, "winterfell_amd"), "-lwinterfell_hip",
-           "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "winterfell_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle")]
+           "-L" + os.path.join(ROOT, "oracle"), "-loracle", "-Wl,-rpath," + os.path.join(ROOT, "winterfell_amd"), "-Wl,-rpath," + os.path.join(ROOT, "oracle"), "-lpthread"]
     subprocess.check_call(cmd)
 
 

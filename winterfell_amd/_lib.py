@@ -62,6 +62,15 @@ _PROTOS = {
     "wf_fri_layer_commit": [_vp, _int, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "wf_fri_apply_drp": [_vp, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "wf_fri_apply_drp_rows": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
+    "wf_comm_get_unique_id": [_vp],
+    "wf_comm_init_rank": [_vp, _vp, _int, _int, _vp],
+    "wf_comm_init_loopback": [_vp, _int, _vp],
+    "wf_comm_destroy": [_vp],
+    "wf_comm_rank": [_vp],
+    "wf_comm_size": [_vp],
+    "wf_comm_all_gather": [_vp, _vp, _vp, _u64],
+    "wf_comm_all_to_all": [_vp, _vp, _vp, _u64],
+    "wf_comm_sharded_commit": [_vp, _int, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _int, _vp, _vp, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -1,0 +1,268 @@
+// Multi-device entry points behind the C ABI: one rank per GPU, the reference's own multi-device commitment (PartitionOptions,
+// air/src/options.rs:391-451; row_matrix.rs:204-223) — every rank owns one partition's columns — with the two exchange steps
+// of SURVEY 8(e) done on the device interconnect:
+//   * all-to-all of the 32-byte partition digests (each rank ends up with every partition's digest of ITS row range),
+//   * all-gather of the G sub-roots (the top log2 G levels are recomputed on every rank).
+// Transports:
+//   RCCL      one process per GPU (or one thread per GPU): ncclCommInitRank on the context's device, collectives on the
+//             context's stream.  librccl is dlopen()ed on first use — a process that already holds an RCCL (PyTorch ships its
+//             own copy) is not handed a second one at load time, and a single-GPU user never loads it at all.
+//   loopback  all ranks are threads of THIS process (any mix of devices, including several logical ranks on one GPU): the
+//             collectives are peer copies between the ranks' buffers around a thread barrier.  This is how the sharded path is
+//             exercised rank for rank on a one-GPU box (tests/test_gpu_comm.py), and a fallback for single-process
+//             multi-GPU hosts without RCCL.
+#include <dlfcn.h>
+#include <pthread.h>
+#include <string.h>
+
+#include <atomic>
+#include <vector>
+
+#include "wf_internal.h"
+
+namespace {
+
+// ---- the slice of the RCCL API used here (rccl.h: ncclGetUniqueId :187, ncclCommInitRank :220, ncclCommDestroy :260,
+// ncclAllGather :678, ncclAllToAll :790; ncclUint8 = 1) ------------------------------------------------------------------------
+struct RcclId {
+    char internal[WF_COMM_ID_BYTES];
+};
+typedef void *RcclComm;
+struct Rccl {
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(RcclComm *, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(RcclComm) = nullptr;
+    int (*AllGather)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
+    int (*AllToAll)(const void *, void *, size_t, int, RcclComm, hipStream_t) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::atomic<bool> tried{false};
+    static pthread_mutex_t mu = PTHREAD_MUTEX_INITIALIZER;
+    if (tried.load()) return r;
+    pthread_mutex_lock(&mu);
+    if (!tried.load()) {
+        void *h = nullptr;
+        // an RCCL that is already mapped (PyTorch's) wins; otherwise the ROCm one
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (h) break;
+        }
+        if (!h)
+            for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+                h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+                if (h) break;
+            }
+        if (h) {
+            r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+            r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+            r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
+            r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
+            r.AllToAll = (decltype(r.AllToAll))dlsym(h, "ncclAllToAll");
+            r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.AllToAll;
+        }
+        tried.store(true);
+    }
+    pthread_mutex_unlock(&mu);
+    return r;
+}
+
+// ---- loopback transport: shared by the `world` ranks of one wf_comm_init_loopback call --------------------------------------
+struct Loopback {
+    int world = 0;
+    pthread_barrier_t bar;
+    std::vector<const void *> send;      // what every rank published for the collective in flight
+    std::atomic<int> refs{0};
+};
+
+}  // namespace
+
+struct wf_comm {
+    wf_ctx *ctx = nullptr;
+    int rank = 0, world = 1;
+    RcclComm nccl = nullptr;             // RCCL transport
+    Loopback *loop = nullptr;            // loopback transport
+};
+
+extern "C" int wf_comm_get_unique_id(uint8_t *id) {
+    if (!id) return WF_ERR_INVALID_ARG;
+    Rccl &r = rccl();
+    if (!r.ok) return WF_ERR_UNSUPPORTED;
+    RcclId u;
+    if (r.GetUniqueId(&u) != 0) return WF_ERR_HIP;
+    memcpy(id, u.internal, WF_COMM_ID_BYTES);
+    return WF_OK;
+}
+
+extern "C" int wf_comm_init_rank(wf_ctx *ctx, const uint8_t *id, int rank, int world, wf_comm **out) {
+    if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return WF_ERR_INVALID_ARG;
+    Rccl &r = rccl();
+    if (!r.ok) return WF_ERR_UNSUPPORTED;
+    WF_HIP(hipSetDevice(ctx->device));
+    RcclId u;
+    memcpy(u.internal, id, WF_COMM_ID_BYTES);
+    RcclComm c = nullptr;
+    if (r.CommInitRank(&c, world, u, rank) != 0) return WF_ERR_HIP;
+    wf_comm *cm = new wf_comm();
+    cm->ctx = ctx;
+    cm->rank = rank;
+    cm->world = world;
+    cm->nccl = c;
+    *out = cm;
+    return WF_OK;
+}
+
+extern "C" int wf_comm_init_loopback(wf_ctx *const *ctxs, int world, wf_comm **out) {
+    if (!ctxs || !out || world < 1) return WF_ERR_INVALID_ARG;
+    for (int i = 0; i < world; i++)
+        if (!ctxs[i]) return WF_ERR_INVALID_ARG;
+    Loopback *lb = new Loopback();
+    lb->world = world;
+    lb->send.assign(world, nullptr);
+    pthread_barrier_init(&lb->bar, nullptr, (unsigned)world);
+    lb->refs.store(world);
+    for (int i = 0; i < world; i++) {
+        wf_comm *cm = new wf_comm();
+        cm->ctx = ctxs[i];
+        cm->rank = i;
+        cm->world = world;
+        cm->loop = lb;
+        out[i] = cm;
+    }
+    return WF_OK;
+}
+
+extern "C" int wf_comm_destroy(wf_comm *cm) {
+    if (!cm) return WF_ERR_INVALID_ARG;
+    if (cm->nccl) (void)rccl().CommDestroy(cm->nccl);
+    if (cm->loop && cm->loop->refs.fetch_sub(1) == 1) {
+        pthread_barrier_destroy(&cm->loop->bar);
+        delete cm->loop;
+    }
+    delete cm;
+    return WF_OK;
+}
+
+extern "C" int wf_comm_rank(const wf_comm *cm) { return cm ? cm->rank : -1; }
+extern "C" int wf_comm_size(const wf_comm *cm) { return cm ? cm->world : -1; }
+
+// every rank contributes `bytes` bytes; d_recv gets world * bytes, rank order
+extern "C" int wf_comm_all_gather(wf_comm *cm, const void *d_send, void *d_recv, uint64_t bytes) {
+    if (!cm || !d_send || !d_recv || bytes == 0) return WF_ERR_INVALID_ARG;
+    wf_ctx *ctx = cm->ctx;
+    if (cm->nccl) {
+        if (rccl().AllGather(d_send, d_recv, bytes, /*ncclUint8*/ 1, cm->nccl, ctx->stream) != 0) return WF_ERR_HIP;
+        return WF_OK;
+    }
+    if (!cm->loop) {                                    // a communicator of one rank
+        WF_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return WF_OK;
+    }
+    Loopback *lb = cm->loop;
+    WF_HIP(hipStreamSynchronize(ctx->stream));          // what this rank publishes is complete
+    lb->send[cm->rank] = d_send;
+    pthread_barrier_wait(&lb->bar);
+    for (int k = 0; k < lb->world; k++)
+        WF_HIP(hipMemcpyAsync((uint8_t *)d_recv + (size_t)k * bytes, lb->send[k], bytes, hipMemcpyDefault, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));          // nobody reuses a send buffer before every reader is done
+    pthread_barrier_wait(&lb->bar);
+    return WF_OK;
+}
+
+// d_send holds `world` blocks of `bytes` bytes, block k goes to rank k; d_recv block k comes from rank k (distinct buffers)
+extern "C" int wf_comm_all_to_all(wf_comm *cm, const void *d_send, void *d_recv, uint64_t bytes) {
+    if (!cm || !d_send || !d_recv || bytes == 0 || d_send == d_recv) return WF_ERR_INVALID_ARG;
+    wf_ctx *ctx = cm->ctx;
+    if (cm->nccl) {
+        if (rccl().AllToAll(d_send, d_recv, bytes, 1, cm->nccl, ctx->stream) != 0) return WF_ERR_HIP;
+        return WF_OK;
+    }
+    if (!cm->loop) {
+        WF_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+        return WF_OK;
+    }
+    Loopback *lb = cm->loop;
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    lb->send[cm->rank] = d_send;
+    pthread_barrier_wait(&lb->bar);
+    for (int k = 0; k < lb->world; k++)
+        WF_HIP(hipMemcpyAsync((uint8_t *)d_recv + (size_t)k * bytes, (const uint8_t *)lb->send[k] + (size_t)cm->rank * bytes, bytes,
+                              hipMemcpyDefault, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    pthread_barrier_wait(&lb->bar);
+    return WF_OK;
+}
+
+namespace {
+// [k][row] -> [row][k] on 32-byte digests (what wf_hash_merge_many_batch reads)
+__global__ __launch_bounds__(256) void regroup_digests_kernel(const uint4 *in, uint4 *out, uint64_t rows, uint32_t k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one 16-byte half of a digest
+    if (i >= rows * k * 2) return;
+    const uint64_t half = i & 1, d = i >> 1, row = d / k, part = d % k;
+    out[i] = in[(part * rows + row) * 2 + half];
+}
+}  // namespace
+
+// Column-sharded trace commitment, this rank's part (call it on every rank).  The rank holds partition `rank` of the columns:
+// d_trace_shard = shard_cols columns of 2^log_n evaluations.  Output, all on this rank's device:
+//   d_trace_shard  the columns' interpolation polynomials (in place, unless skip_interpolate)
+//   d_lde_shard    the shard's LDE, row-major [N = 2^(log_n + log_blowup)][row width of shard_cols]
+//   d_leaves       the leaves of this rank's row range [rank N/G, (rank + 1) N/G): merge_many over the G partition digests
+//   d_nodes        the subtree over those leaves, heap order (N/G digests)
+//   d_top          the top tree over the G sub-roots, heap order (G digests; d_top[1] is the root), identical on every rank
+// The result is node for node the single-device commitment under PartitionOptions(G, hash_rate) with shard_cols columns per
+// partition (G = 1: the plain row hashes — partition_size == num_cols, row_matrix.rs:193).
+extern "C" int wf_comm_sharded_commit(wf_comm *cm, int hash, int field, uint32_t ext_degree, void *d_trace_shard, uint32_t shard_cols,
+                                      uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, int skip_interpolate,
+                                      void *d_lde_shard, void *d_leaves, void *d_nodes, void *d_top, void *h_root) {
+    if (!cm || !d_trace_shard || !d_lde_shard || !d_leaves || !d_nodes || !d_top || shard_cols == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
+    wf_ctx *ctx = cm->ctx;
+    const uint32_t G = (uint32_t)cm->world;
+    const uint64_t N = 1ull << (log_n + log_blowup);
+    if (G & (G - 1)) return WF_ERR_NOT_POWER_OF_TWO;     // the sub-trees must tile a binary tree
+    if (N % G) return WF_ERR_INVALID_ARG;
+    const uint64_t per = N / G;
+    WF_HIP(hipSetDevice(ctx->device));
+    if (!skip_interpolate) WF_TRY(wf_interpolate_columns(ctx, field, ext_degree, d_trace_shard, shard_cols, col_stride, log_n));
+    WF_TRY(wf_evaluate_polys_over(ctx, field, ext_degree, d_trace_shard, shard_cols, col_stride, log_n, log_blowup, h_offset, d_lde_shard));
+    const uint64_t rw = wf_row_width(shard_cols, ext_degree);
+    if (G == 1) {
+        WF_TRY(wf_hash_rows(ctx, hash, field, ext_degree, d_lde_shard, N, rw, shard_cols * ext_degree, 1, 1, d_leaves));
+    } else {
+        void *digests, *recv, *grouped;
+        WF_TRY(wf_malloc(ctx, N * 32, &digests));
+        WF_TRY(wf_malloc(ctx, N * 32, &recv));
+        WF_TRY(wf_malloc(ctx, N * 32, &grouped));
+        // this partition's digest of every row, blocks of `per` rows = the row ranges of the ranks
+        WF_TRY(wf_hash_rows(ctx, hash, field, ext_degree, d_lde_shard, N, rw, shard_cols * ext_degree, 1, 1, digests));
+        WF_TRY(wf_comm_all_to_all(cm, digests, recv, per * 32));                       // recv[k][row]: partition k, my rows
+        hipLaunchKernelGGL(regroup_digests_kernel, dim3((uint32_t)((per * G * 2 + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)recv,
+                           (uint4 *)grouped, per, G);
+        WF_HIP(hipGetLastError());
+        WF_TRY(wf_hash_merge_many_batch(ctx, hash, grouped, per, G, d_leaves));        // leaf = merge_many(partition digests)
+        WF_TRY(wf_free(ctx, digests));
+        WF_TRY(wf_free(ctx, recv));
+        WF_TRY(wf_free(ctx, grouped));
+    }
+    const void *sub_root = d_leaves;
+    if (per > 1) {
+        WF_TRY(wf_merkle_build(ctx, hash, d_leaves, per, d_nodes));
+        sub_root = (const uint8_t *)d_nodes + 32;
+    } else {
+        WF_HIP(hipMemcpyAsync(d_nodes, d_leaves, 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (G == 1) {
+        WF_HIP(hipMemcpyAsync((uint8_t *)d_top, sub_root, 32, hipMemcpyDeviceToDevice, ctx->stream));
+        if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, sub_root, 32));
+        return WF_OK;
+    }
+    void *roots;
+    WF_TRY(wf_malloc(ctx, (size_t)G * 32, &roots));
+    WF_TRY(wf_comm_all_gather(cm, sub_root, roots, 32));
+    WF_TRY(wf_merkle_build(ctx, hash, roots, G, d_top));
+    WF_TRY(wf_free(ctx, roots));
+    if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_top + 32, 32));
+    return WF_OK;
+}
