@@ -66,6 +66,7 @@ struct HBlake3 {
     static constexpr bool COOP = false;
     // levels reduced per Merkle launch: BLAKE3 merges are cheap, so a workgroup walks 10 levels through LDS
     static constexpr uint32_t STAGE_LEVELS = WF_B3_STAGE_LEVELS;
+    static constexpr bool WAVE_TREE = true;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_blake3"; }
     static const char *merkle_name() { return "merkle_stage_blake3"; }
     static const char *grind_name() { return "grind_blake3"; }
@@ -117,6 +118,7 @@ struct HBlake3_192 {
     }
     static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = WF_B3_STAGE_LEVELS;
+    static constexpr bool WAVE_TREE = true;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_blake3_192"; }
     static const char *merkle_name() { return "merkle_stage_blake3_192"; }
     static const char *grind_name() { return "grind_blake3_192"; }
@@ -167,6 +169,7 @@ struct HRpJive {
     static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
     typedef rcoop::CoopRpJive Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;      // as for Rp64_256: one full-width level per launch
+    static constexpr bool WAVE_TREE = false;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_rpjive"; }
     static const char *merkle_name() { return "merkle_stage_rpjive"; }
     static const char *grind_name() { return "grind_rpjive"; }
@@ -224,6 +227,7 @@ struct HRp62 {
     static constexpr bool COOP = true;              // small batches: one state word per lane (rescue_coop.cuh)
     typedef rcoop::CoopRp62 Coop;
     static constexpr uint32_t STAGE_LEVELS = 1;
+    static constexpr bool WAVE_TREE = false;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_rp62"; }
     static const char *merkle_name() { return "merkle_stage_rp62"; }
     static const char *grind_name() { return "grind_rp62"; }
@@ -306,6 +310,7 @@ struct HSha3 {
     }
     static constexpr bool COOP = false;
     static constexpr uint32_t STAGE_LEVELS = 8;
+    static constexpr bool WAVE_TREE = false;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_sha3"; }
     static const char *merkle_name() { return "merkle_stage_sha3"; }
     static const char *grind_name() { return "grind_sha3"; }
@@ -351,6 +356,7 @@ struct HRp64 {
     // a Rescue merge is ~6400 modmuls (0.2 ms of one wave): the nearly empty upper levels of a multi-level workgroup
     // would serialise ten such latencies per workgroup, so the tree is built one full-width level per launch
     static constexpr uint32_t STAGE_LEVELS = 1;
+    static constexpr bool WAVE_TREE = false;    // barrier-free wavefront Merkle stage (merkle_wave_kernel)
     static const char *row_name() { return "hash_rows_rp64"; }
     static const char *merkle_name() { return "merkle_stage_rp64"; }
     static const char *grind_name() { return "grind_rp64"; }
@@ -599,6 +605,98 @@ __global__ __launch_bounds__(256) void merkle_stage4k_kernel(const void *in, voi
         src = dst;
         dst = (t == top) ? bufB : t;
     }
+}
+
+// Barrier-free Merkle stage for the byte hashers: every WAVEFRONT owns a contiguous run of 128 * 2^T input digests and builds
+// the T + 1 levels above them with all 64 lanes busy at every level, no LDS buffer and no workgroup barrier.
+//   level 0: lane L merges input pair P0 + 64 b + L of batch b (coalesced 64-byte loads), b = 0 .. 2^T - 1;
+//   level l: two level-(l-1) sets X, Y of 64 sibling-adjacent digests (Y follows X in the tree) are re-dealt so that lanes
+//            0..31 hold the 32 sibling pairs of X and lanes 32..63 those of Y — ds_bpermute through the LDS crossbar (no LDS
+//            memory), one gather per word and side after X / Y have been interleaved by lane parity (a quad-permute DPP move
+//            and a select) — and merged: 64 merges,
+//            64 consecutive nodes of level l, stored coalesced.
+// The sets are produced depth first (a two-iteration loop per level, so the code holds T + 1 compressions, not 2^T), which keeps
+// T digests live.  The stage kernels above serialise the thin upper levels on one wavefront behind barriers (a 4096-input
+// workgroup's critical path is 28 compressions for 16 per wavefront of work: the BLAKE3 tree ran at half the 55e9
+// compressions/s the arithmetic sustains, tools/microbench_blake3.hip); here a launch of 2^23 leaves is 31/32 of the tree at
+// full lane utilisation.
+// the two level-0 sets under one level-1 set: both loads are issued before the first compression, so that a wavefront has 128
+// bytes per lane in flight while it hashes (level 0 is where the input stream enters)
+template <class H>
+struct WaveTreeLeaves {
+    static __device__ __forceinline__ void build2(const void *in, void *nodes, uint64_t count, uint64_t pair0, uint32_t set, uint32_t lane,
+                                                  uint32_t (&x)[8], uint32_t (&y)[8]) {
+        uint32_t m0[16], m1[16];
+        const uint64_t p0 = pair0 + (uint64_t)(2 * set) * 64 + lane, p1 = p0 + 64;
+        load_pair(in, p0, m0);
+        load_pair(in, p1, m1);
+        H::merge(m0, x);
+        store_digest(nodes, (count >> 1) + p0, x);
+        H::merge(m1, y);
+        store_digest(nodes, (count >> 1) + p1, y);
+    }
+};
+
+template <class H, int L>
+struct WaveTree {
+    // returns, in d, lane `lane`'s node of the 64-node set number `set` (counted within the wave's run) of level L
+    static __device__ __forceinline__ void build(const void *in, void *nodes, uint64_t count, uint64_t pair0, uint32_t set, uint32_t lane,
+                                                 uint32_t (&d)[8]) {
+        uint32_t x[8], y[8];
+        if constexpr (L == 1) {
+            WaveTreeLeaves<H>::build2(in, nodes, count, pair0, set, lane, x, y);
+        } else {
+#pragma unroll 1
+            for (uint32_t h = 0; h < 2; h++) {
+                uint32_t c[8];
+                WaveTree<H, L - 1>::build(in, nodes, count, pair0, 2 * set + h, lane, c);
+                if (h == 0) {
+#pragma unroll
+                    for (int w = 0; w < 8; w++) x[w] = c[w];
+                } else {
+#pragma unroll
+                    for (int w = 0; w < 8; w++) y[w] = c[w];
+                }
+            }
+        }
+        // lanes < 32: (X[2 lane], X[2 lane + 1]); lanes >= 32: (Y[2 (lane - 32)], Y[2 (lane - 32) + 1]).
+        // u = X on even lanes, Y[s - 1] on odd lanes s;  v = X on odd lanes, Y[s + 1] on even lanes s
+        uint32_t m[16];
+        const uint32_t j = lane & 31u, hi = lane >> 5;
+        const int src_l = (int)((2 * j + hi) << 2), src_r = (int)((2 * j + 1 - hi) << 2);
+        const bool odd = lane & 1u;
+#pragma unroll
+        for (int w = 0; w < 8; w++) {
+            // quad_perm [0,0,2,2]: odd lanes read their left neighbour; [1,1,3,3]: even lanes read their right neighbour
+            const uint32_t yprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y[w], 0xA0 /* quad_perm:[0,0,2,2] */, 0xf, 0xf, false);
+            const uint32_t ynext = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)y[w], 0xF5 /* quad_perm:[1,1,3,3] */, 0xf, 0xf, false);
+            const uint32_t u = odd ? yprev : x[w];
+            const uint32_t v = odd ? x[w] : ynext;
+            m[w] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_l, (int)u);
+            m[8 + w] = (uint32_t)__builtin_amdgcn_ds_bpermute(src_r, (int)v);
+        }
+        H::merge(m, d);
+        store_digest(nodes, (count >> (L + 1)) + (pair0 >> L) + (uint64_t)set * 64 + lane, d);
+    }
+};
+template <class H>
+struct WaveTree<H, 0> {
+    static __device__ __forceinline__ void build(const void *in, void *nodes, uint64_t count, uint64_t pair0, uint32_t set, uint32_t lane,
+                                                 uint32_t (&d)[8]) {
+        uint32_t m[16];
+        const uint64_t pr = pair0 + (uint64_t)set * 64 + lane;
+        load_pair(in, pr, m);
+        H::merge(m, d);
+        store_digest(nodes, (count >> 1) + pr, d);
+    }
+};
+
+template <class H, int T>
+__global__ __launch_bounds__(256) void merkle_wave_kernel(const void *in, void *nodes, uint64_t count) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t d[8];
+    WaveTree<H, T>::build(in, nodes, count, wave << (6 + T), 0, lane, d);
 }
 
 __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint32_t take_bytes, const uint64_t *pos,
@@ -860,6 +958,30 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
             wf_prof_end(ctx);
             WF_HIP(hipGetLastError());
             count = half;
+            in = (const uint8_t *)nodes + count * 32;
+            continue;
+        }
+        if (H::WAVE_TREE && count >= (1u << 20)) {
+            // T + 1 levels per launch, 128 * 2^T inputs per wavefront, all lanes busy at every level; T as large as still leaves
+            // four wavefronts per SIMD (4096 on the chip): 2^23 inputs and up take five levels per launch
+            uint32_t lg = 0;
+            while ((2ull << lg) <= count) lg++;
+            const uint32_t T = lg >= 23 ? 4 : lg - 19;
+            const uint64_t waves = count >> (7 + T);
+            if ((waves + 3) / 4 > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            wf_prof_begin(ctx, H::merkle_name());
+            if constexpr (H::WAVE_TREE) {
+                const dim3 grid((uint32_t)((waves + 3) / 4));
+                switch (T) {
+                    case 1: hipLaunchKernelGGL((merkle_wave_kernel<H, 1>), grid, dim3(256), 0, ctx->stream, (const void *)in, nodes, count); break;
+                    case 2: hipLaunchKernelGGL((merkle_wave_kernel<H, 2>), grid, dim3(256), 0, ctx->stream, (const void *)in, nodes, count); break;
+                    case 3: hipLaunchKernelGGL((merkle_wave_kernel<H, 3>), grid, dim3(256), 0, ctx->stream, (const void *)in, nodes, count); break;
+                    default: hipLaunchKernelGGL((merkle_wave_kernel<H, 4>), grid, dim3(256), 0, ctx->stream, (const void *)in, nodes, count); break;
+                }
+            }
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            count >>= T + 1;
             in = (const uint8_t *)nodes + count * 32;
             continue;
         }
