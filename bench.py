@@ -308,7 +308,9 @@ def main():
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/<round>/bench_pmc_summary.json)",
-            "limiter": "VALU issue (SQ_ACTIVE_INST_VALU x 4 cycles = 0.8 of the SIMD-cycles of a launch at the nominal 2.4 GHz; HBM traffic = 1.0x the data per pass; see DESIGN.md section 5)",
+            "limiter": "memory-level parallelism of the tile passes, not instruction issue (round 2: removing the twiddle arithmetic changes the "
+                       "time by 3 %, a 4-pass radix-64 plan at 6 waves/SIMD still takes 67 us per pass; a pure read-modify-write of the same tiles "
+                       "takes 50 us per pass = 5.4 TB/s); HBM traffic = 1.02x the data per pass, three passes; see DESIGN.md section 5",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,

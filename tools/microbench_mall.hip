@@ -64,7 +64,12 @@ static void run(size_t bytes, bool pingpong, bool tile) {
     hipFree(b);
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc > 1) {   // "calib": one known byte count per access width, beyond every cache (for the rocprofv3 counter calibration)
+        run<uint2>((size_t)1024 << 20, true, false);
+        run<uint4>((size_t)1024 << 20, true, false);
+        return 0;
+    }
     for (size_t mib : {16, 32, 64, 128, 192, 256, 512, 1024}) {
         for (int tile = 0; tile < 2; tile++) {
             run<uint2>(mib << 20, false, tile);

@@ -1,9 +1,9 @@
 #!/bin/bash
-# Run ON THE GPU BOX (via gpurun) from the repo root:  tools/profile_round.sh r01
+# Run ON THE GPU BOX (via gpurun) from the repo root:  tools/profile_round.sh r02
 # Produces under gpurun_out/profiles/<round>/: the plain bench line, the rocprofv3 --kernel-trace --stats summary of the
 # same bench command, and the PMC summary (separate --pmc passes, no tracing options combined with them).
 set -u
-R=${1:-r01}
+R=${1:-r02}
 OUT=gpurun_out/profiles/$R
 RAW=gpurun_out/prof_raw_$R
 mkdir -p "$OUT" "$RAW"
@@ -16,3 +16,10 @@ rocprofv3 --pmc WRITE_SIZE -d "$RAW/pmc_write" -o $R --output-format csv -- pyth
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$RAW/pmc_sq" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 python tools/summarize_pmc.py "$RAW" $R > "$OUT/bench_pmc_summary.json"
 cut -c1-400 "$OUT/bench_n1.json"
+
+# FETCH_SIZE / WRITE_SIZE calibration in this code's own access width (MI355X_MICROARCH.md: the x2 FETCH_SIZE correction is
+# documented for 16-byte-per-lane loads only): a read-modify-write of a known byte count with 8-byte and 16-byte lanes
+rocprofv3 --pmc FETCH_SIZE -d "$RAW/cal_fetch" -o $R --output-format csv -- tools/microbench_mall.bin calib > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE -d "$RAW/cal_write" -o $R --output-format csv -- tools/microbench_mall.bin calib > /dev/null 2>&1
+python tools/summarize_calibration.py "$RAW" $R > "$OUT/pmc_calibration.json"
+cat "$OUT/pmc_calibration.json"
