@@ -221,10 +221,11 @@ def prove(name, fld, hasher_id, n, options):
     deep_evals = fld.evaluate_poly_with_offset(deep, offset, b, D)
     # 5. FRI commit phase
     N = options.fri_folding_factor
-    fri_roots, alphas, evals, length = [], [], deep_evals, n * b
+    fri_roots, alphas, evals, length, fri_layers = [], [], deep_evals, n * b, []
     for _ in range(int(orc.fri_num_layers(n * b, N, b, options.fri_remainder_max_degree))):
         transposed = fld.transpose_slice(evals, N, D)
-        _, lnodes = fld.fri_layer_commit(hasher_id, transposed, N, D)
+        lleaves, lnodes = fld.fri_layer_commit(hasher_id, transposed, N, D)
+        fri_layers.append((np.asarray(transposed).reshape(length // N, N * ew), lleaves, lnodes))
         fri_roots.append(lnodes[1].copy())
         coin.reseed(lnodes[1])
         alpha = coin.draw(D)
@@ -245,5 +246,129 @@ def prove(name, fld, hasher_id, n, options):
                composition_poly=cpoly, ood_point=z, ood_trace_frame=(t_cur, t_next), ood_constraint_frame=(q_cur, q_next),
                deep_coefficients=(dc_t, dc_c), fri_roots=fri_roots, fri_alphas=alphas, fri_remainder=remainder,
                fri_remainder_commitment=rem_commitment, pow_seed=pow_seed, pow_nonce=nonce, query_positions=positions,
-               trace_lde=lde, constraint_lde=q_lde, num_composition_columns=ncols)
+               trace_lde=lde, constraint_lde=q_lde, num_composition_columns=ncols,
+               trace_leaves=leaves, trace_nodes=nodes, constraint_leaves=q_leaves, constraint_nodes=q_nodes, fri_layers=fri_layers,
+               width=width, n=n, num_constraints=na + nt)
     return art
+
+
+# ---- Proof::to_bytes (air/src/proof/mod.rs:189-199), written from the reference's Serializable impls ------------------------------
+def vint(value):
+    """ByteWriter::write_usize (utils/core/src/serde/byte_writer.rs:77-91): 1 + floor(bits / 7) bytes, the count in unary in the low
+    bits of the first byte; nine bytes (a zero byte + the u64) from 2^56 on."""
+    nbytes = 1
+    while nbytes < 9 and value >> (7 * nbytes):
+        nbytes += 1
+    if nbytes == 9:
+        return b"\x00" + value.to_bytes(8, "little")
+    return (((value << 1) | 1) << (nbytes - 1)).to_bytes(nbytes, "little")
+
+
+def _elem_bytes(fld, words):
+    w = np.ascontiguousarray(words, dtype=np.uint64).reshape(-1)
+    return orc.f64_to_int(w).tobytes() if fld.name == "f64t" else w.tobytes()
+
+
+def _single_proof(leaves, nodes, index):
+    """MerkleTree::prove (crypto/src/merkle/mod.rs:217-234): [leaf, sibling leaf, then the sibling node of every ancestor]."""
+    n = leaves.shape[0]
+    out = [leaves[index], leaves[index ^ 1]]
+    k = (index + n) >> 1
+    while k > 1:
+        out.append(nodes[k ^ 1])
+        k >>= 1
+    return out
+
+
+def batch_proof(leaves, nodes, indexes):
+    """BatchMerkleProof::from_single_proofs (crypto/src/merkle/proofs.rs:38-108) over the single openings of `indexes` — the
+    reference's OTHER way of building the proof (the product uses MerkleTree::prove_batch).  A literal restatement, including the
+    placement rule: at every level a chain's sibling goes into the node list at the chain's CURRENT position among the surviving
+    chains (`nodes[i].push`), not into the list of the leaf it started from.  Returns (depth, [node lists])."""
+    n = leaves.shape[0]
+    depth = n.bit_length() - 1
+    proofs = {i: _single_proof(leaves, nodes, i)[1:] for i in indexes}     # .1 of MerkleTreeOpening: [sibling leaf, nodes going up]
+    order = sorted(proofs)
+    node_lists, proof_map = [], {}
+    i = 0
+    while i < len(order):
+        first = order[i]
+        if i + 1 < len(order) and first % 2 == 0 and order[i + 1] == first + 1:
+            node_lists.append([])
+            i += 1
+        else:
+            node_lists.append([proofs[first][0]])
+        proof_map[order[i] >> 1] = proofs[first]                            # `proofs[i]` AFTER the increment in the reference...
+        i += 1
+    # (the reference inserts proofs[i] with the incremented i, i.e. the SECOND sibling's path; both paths agree above the leaf level)
+    for d in range(1, depth):
+        keys = sorted(proof_map)
+        nxt = {}
+        i = 0
+        while i < len(keys):
+            index = keys[i]
+            path = proof_map[index]
+            if i + 1 < len(keys) and index % 2 == 0 and keys[i + 1] == index + 1:
+                i += 1
+            else:
+                node_lists[i].append(path[d])
+            nxt[index >> 1] = path
+            i += 1
+        proof_map = nxt
+    return depth, node_lists
+
+
+def _batch_proof_bytes(h, leaves, nodes, indexes):
+    depth, lists = batch_proof(leaves, nodes, indexes)
+    out = bytes([depth]) + vint(len(lists))
+    for lst in lists:
+        out += vint(len(lst)) + b"".join(h.digest_as_bytes(d) for d in lst)
+    return out
+
+
+def _queries_bytes(fld, h, rows, leaves, nodes, positions):
+    values = _elem_bytes(fld, rows)
+    paths = _batch_proof_bytes(h, leaves, nodes, positions)
+    return vint(len(values)) + values + vint(len(paths)) + paths
+
+
+def fold_positions(positions, source_domain_size, folding):
+    target = source_domain_size // folding
+    out = []
+    for p in positions:
+        q = p % target
+        if q not in out:
+            out.append(q)
+    return out
+
+
+def proof_to_bytes(art, fld, hasher_id, options):
+    h = Hasher(hasher_id, fld)
+    D, W, N = options.field_extension, fld.W, options.fri_folding_factor
+    ew = D * W
+    n, width, pos = art["n"], art["width"], art["query_positions"]
+    modulus = fld.M.to_bytes(8 * W, "little")
+    out = bytes([width, 0, 0, n.bit_length() - 1]) + (0).to_bytes(2, "little")                  # TraceInfo: no aux segment, no metadata
+    out += bytes([len(modulus)]) + modulus
+    out += bytes([options.num_queries, options.blowup_factor, options.grinding_factor, D, N, options.fri_remainder_max_degree, 0, 0, 1, 1])
+    out += vint(art["num_constraints"])
+    out += bytes([len(pos)])
+    com = b"".join(h.digest_as_bytes(c) for c in [art["trace_root"], art["constraint_root"]] + art["fri_roots"] + [art["fri_remainder_commitment"]])
+    out += len(com).to_bytes(2, "little") + com
+    out += _queries_bytes(fld, h, art["trace_lde"][pos][:, :width * W], art["trace_leaves"], art["trace_nodes"], pos)
+    ncols = art["num_composition_columns"]
+    out += _queries_bytes(fld, h, art["constraint_lde"][pos][:, :ncols * ew], art["constraint_leaves"], art["constraint_nodes"], pos)
+    for cur, nxt in (art["ood_trace_frame"], art["ood_constraint_frame"]):
+        st = bytes([2]) + _elem_bytes(fld, cur) + _elem_bytes(fld, nxt)
+        out += len(st).to_bytes(2, "little") + st
+    out += bytes([len(art["fri_layers"])])
+    positions, size = list(pos), n * options.blowup_factor
+    for rows, lleaves, lnodes in art["fri_layers"]:
+        positions = fold_positions(positions, size, N)
+        values = _elem_bytes(fld, rows[positions])
+        paths = _batch_proof_bytes(h, lleaves, lnodes, positions)
+        out += len(values).to_bytes(4, "little") + values + len(paths).to_bytes(4, "little") + paths
+        size //= N
+    rem = _elem_bytes(fld, art["fri_remainder"])
+    out += len(rem).to_bytes(2, "little") + rem + bytes([0])                                       # num_partitions = 1 -> log2 = 0
+    return out + int(art["pow_nonce"]).to_bytes(8, "little")

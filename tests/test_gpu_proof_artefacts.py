@@ -25,7 +25,9 @@ def _run(oracle, example, fname, hname, n, D, num_queries=28, blowup=8, grinding
     hid = {"Blake3_256": 0, "Rp64_256": 1}[hname]
     fld, ofld = {"f64": (fields.f64, oracle.f64t), "f128": (fields.f128, oracle.f128)}[fname]
     # ---- CPU: the oracle's whole prover
-    want = oprover.prove(example, ofld, hid, n, oprover.Options(num_queries, blowup, grinding, D, folding, rem_deg))
+    oopts = oprover.Options(num_queries, blowup, grinding, D, folding, rem_deg)
+    want = oprover.prove(example, ofld, hid, n, oopts)
+    want["proof_bytes"] = oprover.proof_to_bytes(want, ofld, hid, oopts)
     # ---- GPU: the product's prove() on the same trace, public inputs the way the example's PublicInputs::to_elements lists them
     ex = oprover.example(example, ofld, n)
     trace = ex["trace"]
@@ -68,6 +70,12 @@ def _check(want, proof, fld):
     pos = want["query_positions"]
     assert eq(np.asarray(t_rows), want["trace_lde"][pos][:, : np.asarray(t_rows).shape[1]]), "queried trace rows"
     assert eq(np.asarray(c_rows), want["constraint_lde"][pos][:, : np.asarray(c_rows).shape[1]]), "queried constraint rows"
+    # ... and the serialised proof (Proof::to_bytes, air/src/proof/mod.rs:189-199): context, commitments, queries with their batch
+    # Merkle openings (the oracle builds them from single openings, the product with prove_batch), OOD frame, FRI proof, nonce
+    got, exp = proof.to_bytes(), want["proof_bytes"]
+    if got != exp:
+        k = next((i for i in range(min(len(got), len(exp))) if got[i] != exp[i]), min(len(got), len(exp)))
+        raise AssertionError("serialised proofs differ: lengths %d / %d, first difference at byte %d" % (len(got), len(exp), k))
 
 
 @pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 1), ("fib_small", "f64", "Rp64_256", 1 << 8, 2),

@@ -63,3 +63,35 @@ def test_cpu_prover_artefacts_satisfy_the_verifiers_checks(oracle, name, fname, 
     # the remainder has len/blowup coefficients and commits to them
     rem = art["fri_remainder"]
     assert np.array_equal(h.hash_elements(rem.reshape(-1)), art["fri_remainder_commitment"])
+
+
+def test_batch_proof_constructions_agree(oracle):
+    """The oracle builds batch Merkle proofs the reference's second way, BatchMerkleProof::from_single_proofs
+    (crypto/src/merkle/proofs.rs:38-108), the product the first way, MerkleTree::prove_batch (merkle/mod.rs:243-272); the
+    reference's own test asserts that they agree, and so must these two restatements — node for node, list for list (both
+    place a sibling at the chain's current position among the surviving chains, not at the leaf it started from)."""
+    from oracle import prover as op
+    from winterfell_amd import crypto
+    from winterfell_amd.crypto.merkle import MerkleTree
+    rng = np.random.default_rng(5)
+    for n in (8, 64, 1024):
+        leaves = rng.integers(0, 256, (n, 32), dtype=np.uint8)
+        nodes = oracle.merkle_build(0, leaves)
+        tree = MerkleTree.from_raw_parts(crypto.Blake3_256, nodes, leaves)
+        for _ in range(100):
+            idx = sorted({int(v) for v in rng.integers(0, n, int(rng.integers(1, 14)))})
+            depth, lists = op.batch_proof(leaves, nodes, idx)
+            _, bp = tree.prove_batch(idx)
+            assert depth == bp.depth and len(lists) == len(bp.nodes)
+            for a, b in zip(lists, bp.nodes):
+                assert len(a) == len(b) and all(np.array_equal(x, y) for x, y in zip(a, b)), idx
+
+
+def test_usize_encoding(oracle):
+    """ByteWriter::write_usize (utils/core/src/serde/byte_writer.rs:77-91,145-149) in both serialisers."""
+    from oracle import prover as op
+    from winterfell_amd.prover.proof import write_usize
+    assert op.vint(0) == b"\x01" and op.vint(1) == b"\x03" and op.vint(127) == b"\xff" and op.vint(128) == bytes([0x02, 0x02])
+    assert op.vint(2**56 - 1) == b"\x80" + b"\xff" * 7 and op.vint(2**56) == b"\x00" + (2**56).to_bytes(8, "little")
+    for v in list(range(0, 70000, 37)) + [2**k + d for k in range(7, 64, 7) for d in (-1, 0, 1)] + [2**64 - 1]:
+        assert write_usize(v) == op.vint(v), v

@@ -1,8 +1,8 @@
 """Prover::generate_proof (prover/src/lib.rs:275-492) for the built-in AIRs, every data-parallel step on the device.
 
-Returns the pieces a `Proof` is assembled from (commitments, out-of-domain frame, FRI layers + remainder, proof-of-work
-nonce, query positions with the opened rows and batch Merkle proofs); serialising them into the reference's byte format is
-out of scope."""
+Returns a `Proof` (prover/proof.py): the pieces air::proof::Proof is assembled from (context, commitments, out-of-domain
+frame, FRI proof, proof-of-work nonce, the opened rows with their batch Merkle proofs) with `to_bytes()` in the reference's
+wire format, plus the intermediate transcript values the tests compare."""
 import time
 
 from ..fri.prover import FriOptions, FriProver
@@ -11,14 +11,8 @@ from .composer import DeepCompositionPoly, TracePolyTable, composition_poly_ood_
 from .constraint_commitment import build_constraint_commitment
 from .constraints import DefaultConstraintEvaluator
 from .matrix import ColMatrix
+from .proof import Proof
 from .trace_lde import DefaultTraceLde, StarkDomain
-
-
-class Proof:
-    """What prove() produced, by the names of air::proof::Proof's fields where they exist."""
-
-    def __init__(self, **kw):
-        self.__dict__.update(kw)
 
 
 def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_elements, timings=None):
@@ -79,7 +73,7 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
     trace_queries = trace_lde.query(query_positions)
     constraint_queries = constraint_commitment.query(query_positions)
     lap("build_proof_object", t0)
-    return Proof(options=options, commitments=channel.commitments, trace_commitment=trace_lde.get_main_trace_commitment(),
+    return Proof(air=air, hasher=hasher, options=options, commitments=channel.commitments, trace_commitment=trace_lde.get_main_trace_commitment(),
                  constraint_commitment=constraint_commitment.commitment(), ood_point=z, ood_trace_frame=ood_trace_states,
                  ood_constraint_frame=ood_evaluations, constraint_coefficients=evaluator.cc, assertions=evaluator.assertions,
                  deep_coefficients=(cc_trace, cc_constraints), fri_layers=fri_layers, fri_remainder=fri_remainder, fri_proof=fri_proof,
