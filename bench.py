@@ -375,23 +375,20 @@ def main():
             # FRI commit phase (configs[4] shape): 2^24 LDE domain, f64 quadratic extension, folding 4, rem-deg 31
             from winterfell_amd import fri as wfri
 
-            class _Chan:   # deterministic stand-in for the host Fiat-Shamir channel (alpha values do not affect timing)
-                def __init__(self):
-                    self.k = 0
-
-                def commit_fri_layer(self, root):
-                    self.k += 1
-
-                def draw_fri_alpha(self):
-                    return np.array([fields.new(12345 + self.k), fields.new(777 + self.k)], dtype=np.uint64)
-
             ev = ctx.to_device(rng.integers(0, fields.M, (1 << 24) * 2, dtype=np.uint64))
 
             def fri_run():
+                # fri/benches/prover.rs: FriProver::build_layers against a DefaultProverChannel (its coin on the device here)
                 pr = wfri.FriProver(wfri.FriOptions(8, 4, 31), crypto.Blake3_256, ext_degree=2)
-                pr.build_layers(_Chan(), ev)
+                pr.build_layers(wfri.DefaultProverChannel(1 << 24, 32, crypto.Blake3_256, ext_degree=2), ev)
 
             ex["fri_build_layers_ms_2^24_quad_fold4_blake3"] = timed(fri_run, 3)
+
+            def fri_run_host_coin():   # the same with the channel's coin on the host: two small device hashes + round trips per layer
+                pr = wfri.FriProver(wfri.FriOptions(8, 4, 31), crypto.Blake3_256, ext_degree=2)
+                pr.build_layers(wfri.DefaultProverChannel(1 << 24, 32, crypto.Blake3_256, ext_degree=2, device_coin=False), ev)
+
+            ex["fri_build_layers_ms_2^24_quad_fold4_blake3_host_coin"] = timed(fri_run_host_coin, 3)
 
             # ---- HBM rooflines of the other reported rates: algorithmic bytes (SURVEY 8d / BASELINE.md section 4) over the
             # summed kernel durations (HIP events on the launch stream, wf_prof_*) of one call ----

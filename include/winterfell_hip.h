@@ -197,6 +197,29 @@ int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h_seed, uint
 int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grinding_factor, uint64_t first_nonce,
              uint64_t max_nonce, uint64_t *h_nonce);
 
+/* ---- crypto::DefaultRandomCoin with its state on the device (crypto/src/random/default.rs:60-250) ---------------
+ * The coin's state (seed digest, counter) lives in WF_COIN_BYTES of device memory, so that a chain of
+ * commit -> reseed -> draw -> use can be queued without a host round trip per link (wf_fri_build_layers below).  The
+ * host-side coin of an integration hands its state over with wf_coin_init and takes it back with wf_coin_read.
+ *   wf_coin_init    seed := h_seed (32 digest bytes, library layout), counter := 0
+ *   wf_coin_reseed  RandomCoin::reseed (:150-153): seed := merge(seed, d_digest), counter := 0; the digest is also
+ *                   copied to d_digest_copy when that is not NULL (the commitment the caller will put in its proof)
+ *   wf_coin_draw    `count` x RandomCoin::draw::<E> (:185-199) into d_out (count * ext_degree elements, internal form):
+ *                   next() = merge_with_int(seed, ++counter) until the first ELEMENT_BYTES of Digest::as_bytes decode to
+ *                   canonical base elements, at most 1000 times per element
+ *   wf_coin_reseed_draw  reseed with d_digest, then one draw, in one launch (commit_fri_layer + draw_fri_alpha)
+ *   wf_coin_read    waits for the stream; h_seed / h_counter := the state; WF_ERR_NOT_FOUND if a draw used up its 1000
+ *                   tries (the reference's RandomCoinError::FailedToDrawFieldElement) */
+/* state layout: bytes [0, 32) the seed digest, [32, 40) the counter (little-endian u64), [40, 44) non-zero once a draw has
+ * failed, the rest reserved — a caller may also write / read the 64 bytes itself instead of wf_coin_init / wf_coin_read */
+#define WF_COIN_BYTES 64
+int wf_coin_init(wf_ctx *ctx, void *d_coin, const void *h_seed);
+int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d_digest, void *d_digest_copy);
+int wf_coin_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, uint32_t count, void *d_out);
+int wf_coin_reseed_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, const void *d_digest, void *d_digest_copy,
+                        void *d_out);
+int wf_coin_read(wf_ctx *ctx, const void *d_coin, void *h_seed, uint64_t *h_counter);
+
 /* ElementHasher::hash_elements over `count` independent rows (hash/mod.rs:56-64); same layout as wf_hash_rows
  * without partitions. */
 int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,
@@ -290,6 +313,20 @@ int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, c
  * (ext_degree words), both in internal form. */
 int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                      uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded);
+
+/* FriProver::build_layers' loop (fri/src/prover/mod.rs:179-199) against a device-resident coin: for each of the
+ * num_layers layers  build_layer = commit (as wf_fri_layer_commit), channel.commit_fri_layer(root) = coin.reseed(root),
+ * alpha = channel.draw_fri_alpha() = coin.draw::<E>(), apply_drp (as wf_fri_apply_drp) — queued back to back on the
+ * context's stream, nothing waits on the host.  Layer k (k = 0 .. num_layers-1) works on 2^log_len / folding^k points:
+ *   d_transposed[k], d_leaves[k], d_nodes[k]   OUT  the layer's evaluations / row digests / Merkle nodes (kept for the query phase)
+ *   d_folded[k]                                OUT  the next layer's evaluations (d_folded[num_layers-1] is the remainder's input)
+ *   d_roots   OUT num_layers x 32 bytes, d_alphas OUT num_layers x ext_degree elements (what the channel would have seen)
+ * The four pointer arrays are host arrays of device pointers.  The caller reads roots / alphas / the coin back once,
+ * after the loop (the remainder commitment, mod.rs:230-239, is its next step). */
+int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_len,
+                        uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
+                        void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded,
+                        void *d_roots, void *d_alphas);
 
 /* The same fold for `num_rows` consecutive rows, starting at row_start, of a layer whose full domain has 2^log_len
  * points: d_transposed_rows holds only those rows, d_folded receives num_rows elements.  This is what one GPU runs on

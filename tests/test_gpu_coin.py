@@ -1,0 +1,147 @@
+"""The device-resident DefaultRandomCoin (include/winterfell_hip.h: wf_coin_*) and the fused FRI layer loop built on it
+(wf_fri_build_layers): value for value the transcript of the host coin / the oracle's restatement of
+crypto/src/random/default.rs, for every hasher and every field + extension degree a digest can hold."""
+import numpy as np
+import pytest
+
+from conftest import rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def wf():
+    import winterfell_amd
+    from winterfell_amd import crypto, fri
+    from winterfell_amd.math import fields
+    return winterfell_amd.default_context(), crypto, fri, fields
+
+
+def _script(coin_draw, coin_reseed, D, digests):
+    """draw 5, reseed, draw 1, draw 3, reseed, draw 2 -> the drawn words, in order"""
+    out = [coin_draw(D, 5)]
+    coin_reseed(digests[0])
+    out.append(coin_draw(D, 1))
+    out.append(coin_draw(D, 3))
+    coin_reseed(digests[1])
+    out.append(coin_draw(D, 2))
+    return np.concatenate([np.asarray(o, dtype=np.uint64).reshape(-1) for o in out])
+
+
+@pytest.mark.parametrize("hname,fname,D", [("Blake3_256", "f64", 1), ("Blake3_256", "f64", 2), ("Blake3_256", "f64", 3), ("Blake3_256", "f128", 1),
+                                           ("Blake3_256", "f128", 2), ("Rp64_256", "f64", 1), ("Rp64_256", "f64", 2), ("Rp64_256", "f64", 3)])
+def test_device_coin_against_the_oracle_coin(wf, oracle, hname, fname, D):
+    ctx, crypto, fri, fields = wf
+    from oracle import prover as oprover
+    hasher, f = getattr(crypto, hname), getattr(fields, fname)
+    ofld = oracle.f64t if fname == "f64" else oracle.f128
+    seed_words = f.pack([f.new(v) for v in (3, 1 << 40, 77)])
+    ocoin = oprover.Coin(oprover.Hasher(oprover.BLAKE3_256 if hname == "Blake3_256" else oprover.RP64_256, ofld), seed_words)
+    host = crypto.DefaultRandomCoin(hasher, f, seed_words, ctx)
+    assert np.array_equal(host.seed, ocoin.seed)
+    digests = [hasher.hash_elements(f.pack([f.new(k + 1)]), ctx, field=f) for k in range(2)]
+    want = _script(lambda d, c: np.concatenate([ocoin.draw(d) for _ in range(c)]), ocoin.reseed, D, digests)
+    dev = host.to_device()
+    d_digests = [ctx.to_device(d) for d in digests]
+    k = [0]
+
+    def reseed(_):
+        dev.reseed(d_digests[k[0]])
+        k[0] += 1
+    got = _script(lambda d, c: ctx.to_host(dev.draw(d, c)), reseed, D, digests)
+    assert np.array_equal(got, want)
+    seed, counter = dev.read()
+    assert np.array_equal(seed, ocoin.seed) and counter == ocoin.counter
+    # ... and the host coin carries on from there
+    host.take_back(dev)
+    assert np.array_equal(host.draw(D), ocoin.draw(D))
+
+
+@pytest.mark.parametrize("hname,fname,D", [("Sha3_256", "f64", 2), ("Blake3_192", "f64", 3), ("Blake3_192", "f128", 1), ("RpJive64_256", "f64", 2),
+                                           ("Rp62_248", "f62", 1), ("Rp62_248", "f62", 3), ("Sha3_256", "f128", 2)])
+def test_device_coin_against_the_host_coin(wf, hname, fname, D):
+    """the hashers the oracle's Python coin does not wrap: against the host coin, whose every hash is the library's batch entry
+    point checked against the oracle elsewhere (test_gpu_sha3 / blake3_192 / rpjive / rp62)"""
+    ctx, crypto, fri, fields = wf
+    hasher, f = getattr(crypto, hname), getattr(fields, fname)
+    seed_words = f.pack([f.new(v) for v in (5, 6, 7, 8, 9)])
+    host = crypto.DefaultRandomCoin(hasher, f, seed_words, ctx)
+    host.draw(1)                                             # hand over a coin that has already drawn (counter = 1)
+    dev = host.to_device()
+    digests = [hasher.hash_elements(f.pack([f.new(k + 11)]), ctx, field=f) for k in range(2)]
+    want = _script(lambda d, c: np.concatenate([host.draw(d) for _ in range(c)]), host.reseed, D, digests)
+    d_digests = [ctx.to_device(d) for d in digests]
+    k = [0]
+
+    def reseed(_):
+        dev.reseed(d_digests[k[0]])
+        k[0] += 1
+    got = _script(lambda d, c: ctx.to_host(dev.draw(d, c)), reseed, D, digests)
+    assert np.array_equal(got, want)
+    seed, counter = dev.read()
+    assert np.array_equal(seed, host.seed) and counter == host.counter
+
+
+def test_reseed_copies_the_digest_and_rejects_bad_arguments(wf):
+    ctx, crypto, fri, fields = wf
+    import ctypes
+    from winterfell_amd._lib import ptr
+    dev = crypto.DefaultRandomCoin(crypto.Blake3_256, fields.f64, np.zeros(0, dtype=np.uint64), ctx).to_device()
+    dig = ctx.to_device(np.arange(32, dtype=np.uint8))
+    copy = ctx.empty_u8(32)
+    dev.reseed(dig, copy)
+    assert np.array_equal(ctx.to_host(copy), np.arange(32, dtype=np.uint8))
+    lib, out = ctx.lib, ctx.empty_u64(8)
+    # wf_coin_init / wf_coin_read (what a non-Python host uses instead of writing the 64 state bytes itself)
+    st2, seed, counter = ctx.empty_u8(64), np.empty(32, dtype=np.uint8), ctypes.c_uint64(99)
+    ctx.call("wf_coin_init", ptr(st2), np.arange(32, dtype=np.uint8).ctypes.data_as(ctypes.c_void_p))
+    ctx.call("wf_coin_draw", 0, 0, 2, ptr(st2), 3, ptr(out))
+    ctx.call("wf_coin_read", ptr(st2), seed.ctypes.data_as(ctypes.c_void_p), ctypes.byref(counter))
+    host = crypto.DefaultRandomCoin(crypto.Blake3_256, fields.f64, np.zeros(0, dtype=np.uint64), ctx)
+    host.seed, host.counter = np.arange(32, dtype=np.uint8), 0
+    want = np.concatenate([host.draw(2) for _ in range(3)])
+    assert np.array_equal(ctx.to_host(out)[:6], want) and np.array_equal(seed, host.seed) and counter.value == host.counter
+    # commit + draw in one launch
+    ctx.call("wf_coin_reseed_draw", 0, 0, 2, ptr(st2), ptr(dig), None, ptr(out))
+    host.reseed(np.arange(32, dtype=np.uint8))
+    assert np.array_equal(ctx.to_host(out)[:2], host.draw(2))
+    assert lib.wf_coin_draw(ctx.handle, 0, 1, 3, ptr(dev.state), 1, ptr(out)) != 0          # f128 has no cubic extension
+    assert lib.wf_coin_draw(ctx.handle, 0, 7, 1, ptr(dev.state), 1, ptr(out)) != 0          # unknown field
+    assert lib.wf_coin_draw(ctx.handle, 99, 0, 1, ptr(dev.state), 1, ptr(out)) != 0         # unknown hasher
+    assert lib.wf_coin_reseed(ctx.handle, 0, None, ptr(dig), None) != 0
+    assert lib.wf_coin_init(ctx.handle, ptr(dev.state), None) != 0
+
+
+@pytest.mark.parametrize("hname,fname,D,log_len,N,rem_deg", [("Blake3_256", "f64", 2, 16, 4, 31), ("Blake3_256", "f64", 1, 12, 2, 7),
+                                                             ("Sha3_256", "f64", 3, 13, 8, 31), ("Blake3_256", "f128", 2, 12, 4, 15),
+                                                             ("Blake3_192", "f64", 2, 14, 16, 31), ("Blake3_256", "f64", 2, 8, 4, 31)])
+def test_fused_layer_loop_equals_the_layer_by_layer_prover(wf, hname, fname, D, log_len, N, rem_deg):
+    """FriProver.build_layers with the coin on the device (one wf_fri_build_layers call) against the same prover driven layer
+    by layer through a host coin (the path test_gpu_fri.py checks against the oracle): commitments, alphas, every layer's
+    evaluations and tree, the remainder, the coin afterwards."""
+    ctx, crypto, fri, fields = wf
+    hasher, f = getattr(crypto, hname), getattr(fields, fname)
+    n = 1 << log_len
+    rng = np.random.default_rng(4000 + log_len + N)
+    words = rng.integers(0, 1 << 63, (n * D, 2), dtype=np.uint64)
+    ev = f.from_ints([(int(a) | (int(b) << 64)) % f.M for a, b in words])      # any vector folds; FRI's low-degree input is not needed here
+    opts = fri.FriOptions(8, N, rem_deg, field=f)
+    runs = []
+    for device_coin in (True, False):
+        chan = fri.DefaultProverChannel(n, 8, hasher, ext_degree=D, field=f, ctx=ctx, device_coin=device_coin)
+        assert (chan.fri_device_coin() is not None) == device_coin
+        pr = fri.FriProver(opts, hasher, ext_degree=D, ctx=ctx)
+        pr.build_layers(chan, ev.copy())
+        runs.append((chan, pr))
+    (ca, pa), (cb, pb) = runs
+    assert pa.num_layers() == pb.num_layers() == opts.num_fri_layers(n)
+    assert len(ca.commitments) == len(cb.commitments) == pa.num_layers() + 1
+    for x, y in zip(ca.commitments, cb.commitments):
+        assert np.array_equal(x, y)
+    assert len(ca.alphas) == len(cb.alphas) and all(np.array_equal(x, y) for x, y in zip(ca.alphas, cb.alphas))
+    for la, lb in zip(pa.layers, pb.layers):
+        assert np.array_equal(ctx.to_host(la.evaluations), ctx.to_host(lb.evaluations))
+        assert np.array_equal(la.commitment.nodes, lb.commitment.nodes)
+    assert np.array_equal(pa.remainder_poly, pb.remainder_poly)
+    assert np.array_equal(ca.public_coin.seed, cb.public_coin.seed) and ca.public_coin.counter == cb.public_coin.counter
+    assert ca.draw_query_positions(3) == cb.draw_query_positions(3)

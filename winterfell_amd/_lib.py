@@ -62,6 +62,12 @@ _PROTOS = {
     "wf_fri_layer_commit": [_vp, _int, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "wf_fri_apply_drp": [_vp, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "wf_fri_apply_drp_rows": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
+    "wf_fri_build_layers": [_vp, _int, _int, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "wf_coin_init": [_vp, _vp, _vp],
+    "wf_coin_reseed": [_vp, _int, _vp, _vp, _vp],
+    "wf_coin_draw": [_vp, _int, _int, _u32, _vp, _u32, _vp],
+    "wf_coin_reseed_draw": [_vp, _int, _int, _u32, _vp, _vp, _vp, _vp],
+    "wf_coin_read": [_vp, _vp, _vp, ctypes.POINTER(ctypes.c_uint64)],
     "wf_comm_get_unique_id": [_vp],
     "wf_comm_init_rank": [_vp, _vp, _int, _int, _vp],
     "wf_comm_init_loopback": [_vp, _int, _vp],
@@ -202,6 +208,11 @@ class Context:
 
 def ptr(t):
     return _vp(t.data_ptr())
+
+
+def torch_u64():
+    """the dtype the library's 64-bit words are held in on the torch side (the int64 bit container Context.empty_u64 allocates)"""
+    return _torch().int64
 
 
 _default = {}

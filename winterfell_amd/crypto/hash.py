@@ -16,6 +16,9 @@ from ..math import fields
 class _Hasher:
     HASH_ID = None
     COLLISION_RESISTANCE = 128
+    # whether a chain of coin steps is worth queueing as single-lane kernels (crypto/random.py DeviceCoin): yes for the byte
+    # hashers (one compression, ~2 us); a Rescue permutation on one lane costs more than the host round trip it would save
+    DEVICE_COIN = True
 
     @classmethod
     def merge(cls, values, ctx=None):
@@ -145,6 +148,7 @@ def _bytes_to_elements(data, field, strict_index=True):
 class Rp64_256(_Hasher):
     """crypto::hash::Rp64_256 (crypto/src/hash/rescue/rp64_256/mod.rs:123-257)."""
     HASH_ID = WF_HASH_RP64_256
+    DEVICE_COIN = False
 
     @classmethod
     def hash(cls, data, ctx=None):
@@ -172,6 +176,7 @@ class Rp62_248(_Hasher):
     """crypto::hash::Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs:62-239): Rescue-Prime over f62; a digest is four
     f62 words (ElementDigest, digest.rs:16), serialised as 31 bytes."""
     HASH_ID = WF_HASH_RP62_248
+    DEVICE_COIN = False
 
     @classmethod
     def hash_elements(cls, elements, ctx=None, field=fields.f62):

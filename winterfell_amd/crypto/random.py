@@ -9,7 +9,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WfError, default_context
+from .._lib import WfError, default_context, ptr
 
 WF_ERR_NOT_FOUND = 9
 
@@ -93,6 +93,16 @@ class DefaultRandomCoin:
     def check_leading_zeros(self, value):
         return check_leading_zeros(self.hasher, self.seed, value, ctx=self.ctx)
 
+    # ---- hand-over to / from the device-resident coin (include/winterfell_hip.h: wf_coin_*) --------------------------------
+    def to_device(self):
+        """the coin's state as a DeviceCoin: what a chain of reseed / draw steps queued on the stream starts from"""
+        return DeviceCoin(self.hasher, self.field, self.seed, self.counter, self.ctx)
+
+    def take_back(self, device_coin):
+        """continue on the host from where the device coin stopped (waits for the stream)"""
+        self.seed, self.counter = device_coin.read()
+        self._ahead = []
+
     def draw_integers(self, num_values, domain_size, nonce):
         """:209-248: reseed with the nonce, then masked 8-byte heads (duplicates are removed by the caller)."""
         assert domain_size & (domain_size - 1) == 0, "domain size must be a power of two"
@@ -101,3 +111,52 @@ class DefaultRandomCoin:
         self.counter, self._ahead = 0, []
         self.prefetch(num_values)
         return [int.from_bytes(self._next()[:8], "little") & (domain_size - 1) for _ in range(num_values)]
+
+
+class DeviceCoin:
+    """DefaultRandomCoin with its state (seed digest, counter) in device memory: reseed / draw are single-lane kernels queued on
+    the context's stream, so a commit -> reseed -> draw -> use chain (the FRI layers, wf_fri_build_layers) runs without a host
+    round trip per link.  Same transcript as the host coin, value for value."""
+
+    def __init__(self, hasher, field, seed, counter=0, ctx=None):
+        self.hasher, self.field = hasher, field
+        self.ctx = ctx or default_context()
+        # WF_COIN_BYTES = 64: seed digest [0, 32), counter (little-endian u64) [32, 40), "a draw failed" flag (u32) [40, 44)
+        self._image = np.zeros(64, dtype=np.uint8)
+        self._image[:32] = np.ascontiguousarray(seed).view(np.uint8).reshape(32)
+        self._image[32:40] = np.frombuffer(int(counter).to_bytes(8, "little"), dtype=np.uint8)
+        self.state = None                                        # uploaded on first use, or placed by move_to()
+        self._host_image = None
+
+    def _upload(self):
+        if self.state is None:
+            self.state = self.ctx.to_device(self._image)
+        return self.state
+
+    def move_to(self, d_state):
+        """keep the state in the caller's 64 device bytes (so that it comes back with the caller's own read)"""
+        d_state.copy_(self.ctx.to_device(self._image) if self.state is None else self.state)
+        self.state = d_state
+
+    def set_host_image(self, image):
+        """the 64 state bytes as the caller has just read them back: read() then needs no transfer of its own"""
+        self._host_image = np.array(image, dtype=np.uint8, copy=True)
+
+    def reseed(self, d_digest, d_copy=None):
+        """seed = merge(seed, digest) for a digest that is on the device (e.g. nodes[1] of a Merkle tree just built)"""
+        self._host_image = None
+        self.ctx.call("wf_coin_reseed", self.hasher.HASH_ID, ptr(self._upload()), ptr(d_digest), ptr(d_copy) if d_copy is not None else None)
+
+    def draw(self, ext_degree=1, count=1):
+        """`count` draws of an E element -> device tensor of count * ext_degree * W words (internal form)"""
+        self._host_image = None
+        out = self.ctx.empty_u64(count, ext_degree * self.field.W)
+        self.ctx.call("wf_coin_draw", self.hasher.HASH_ID, self.field.ID, ext_degree, ptr(self._upload()), count, ptr(out))
+        return out
+
+    def read(self):
+        """(seed, counter) after everything queued so far; raises like the reference when a draw ran out of tries"""
+        img = self._host_image if self._host_image is not None else self.ctx.to_host(self._upload())
+        if int.from_bytes(img[40:44].tobytes(), "little"):
+            raise RuntimeError("FailedToDrawFieldElement(1000)")
+        return np.array(img[:32], copy=True), int.from_bytes(img[32:40].tobytes(), "little")

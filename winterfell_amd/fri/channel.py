@@ -1,0 +1,47 @@
+"""fri::DefaultProverChannel (fri/src/prover/channel.rs:60-127): the stand-alone channel of the `fri` crate — a public coin
+seeded with no elements, the layer commitments, and the query positions — used by the reference's own FRI tests and
+benchmark (fri/src/prover/tests.rs, fri/benches/prover.rs).  The coin can be handed to the device for the layer loop
+(FriProver.build_layers' fused path), which is what makes `build_layers` one library call here."""
+import numpy as np
+
+from ..crypto.random import DefaultRandomCoin
+from ..math import fields
+
+
+class DefaultProverChannel:
+    def __init__(self, domain_size, num_queries, hasher, ext_degree=1, field=fields.f64, ctx=None, device_coin=True):
+        assert domain_size >= 8, "domain size must be at least 8, but was %d" % domain_size                       # channel.rs:82
+        assert domain_size & (domain_size - 1) == 0, "domain size must be a power of two, but was %d" % domain_size
+        assert num_queries > 0, "number of queries must be greater than zero"
+        self.hasher, self.field, self.D, self.ctx = hasher, field, ext_degree, ctx
+        self.public_coin = DefaultRandomCoin(hasher, field, np.zeros(0, dtype=np.uint64), ctx)                    # RandomCoin::new(&[])
+        self.commitments, self.alphas = [], []
+        self.domain_size, self.num_queries = domain_size, num_queries
+        self._device_coin = device_coin and hasher.DEVICE_COIN
+
+    def draw_query_positions(self, nonce):
+        """channel.rs:103-107"""
+        return self.public_coin.draw_integers(self.num_queries, self.domain_size, nonce)
+
+    def layer_commitments(self):
+        return self.commitments
+
+    # ---- fri::ProverChannel (channel.rs:24-50)
+    def commit_fri_layer(self, layer_root):
+        self.commitments.append(np.array(layer_root, copy=True))
+        self.public_coin.reseed(layer_root)
+
+    def draw_fri_alpha(self):
+        a = self.public_coin.draw(self.D)
+        self.alphas.append(a)
+        return a
+
+    # ---- the same two calls for all the layers, with the coin on the device
+    def fri_device_coin(self):
+        return self.public_coin.to_device() if self._device_coin else None
+
+    def absorb_fri_layers(self, device_coin, roots, alphas):
+        for root, alpha in zip(roots, alphas):
+            self.commitments.append(np.array(root, copy=True))
+            self.alphas.append(np.array(alpha, copy=True))
+        self.public_coin.take_back(device_coin)

@@ -7,7 +7,7 @@ import ctypes
 
 import numpy as np
 
-from .._lib import WF_FIELD_F64, default_context, ptr
+from .._lib import WF_FIELD_F64, default_context, ptr, torch_u64
 from ..crypto.merkle import MerkleTree
 from ..math import fft, fields
 
@@ -69,6 +69,10 @@ class FriProver:
         assert length & (length - 1) == 0
         off = f.element_words(int(self.options.domain_offset()))
         off_p = off.ctypes.data_as(ctypes.c_void_p)
+        coin = channel.fri_device_coin() if hasattr(channel, "fri_device_coin") else None
+        if coin is not None:
+            ev, length = self._build_layers_fused(channel, coin, ev, length, off_p)
+            return self._set_remainder(channel, ev, length)
         for _ in range(self.options.num_fri_layers(length)):
             log_len = length.bit_length() - 1
             rows = length // N
@@ -89,6 +93,42 @@ class FriProver:
             self.layers.append(FriLayer(MerkleTree(self.hasher, leaves, nodes, ctx), transposed))
             ev, length = folded, rows
         self._set_remainder(channel, ev, length)
+
+    def _build_layers_fused(self, channel, coin, ev, length, off_p):
+        """the same loop as one library call against a device-resident coin (wf_fri_build_layers): commit, reseed, draw, fold
+        for every layer are queued back to back; roots, alphas and the coin come back in one read at the end"""
+        ctx, D, N, f = self.ctx, self.D, self.options.folding_factor, self.options.field
+        nl = self.options.num_fri_layers(length)
+        if nl == 0:
+            return ev, length
+        log_len = length.bit_length() - 1
+        ew = D * f.W * 8                                         # bytes per E element
+        # one allocation for every layer's four arrays, one for what comes back (roots | alphas | the coin)
+        sizes, rows = [], length
+        for _ in range(nl):
+            rows //= N
+            sizes.append((rows * N * ew, rows * 32, rows * 32, rows * ew))
+        pool = ctx.empty_u8(sum(sum(t) for t in sizes))
+        tr, lv, nd, fo, at = [], [], [], [], 0
+        for k, (a, b, c, d) in enumerate(sizes):
+            r = b // 32
+            tr.append(pool[at:at + a].view(torch_u64()).view(r, N * D * f.W))
+            lv.append(pool[at + a:at + a + b].view(r, 32))
+            nd.append(pool[at + a + b:at + a + b + c].view(r, 32))
+            fo.append(pool[at + a + b + c:at + a + b + c + d].view(torch_u64()))
+            at += a + b + c + d
+        back = ctx.empty_u8(nl * 32 + nl * ew + 64)
+        roots, alphas, state = back[:nl * 32], back[nl * 32:nl * (32 + ew)], back[nl * (32 + ew):]
+        coin.move_to(state)
+        arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+        ctx.call("wf_fri_build_layers", self.hasher.HASH_ID, f.ID, D, ptr(ev), log_len, N, nl, off_p, ptr(coin.state), arr(tr), arr(lv), arr(nd),
+                 arr(fo), ptr(roots), ptr(alphas))
+        host = ctx.to_host(back)                                 # the one wait of the layer loop
+        coin.set_host_image(host[nl * (32 + ew):])
+        channel.absorb_fri_layers(coin, host[:nl * 32].reshape(nl, 32), host[nl * 32:nl * (32 + ew)].view(np.uint64).reshape(nl, D * f.W))
+        for k in range(nl):
+            self.layers.append(FriLayer(MerkleTree(self.hasher, lv[k], nd[k], ctx), tr[k]))
+        return fo[-1], rows
 
     def _set_remainder(self, channel, ev, length):
         """mod.rs:230-239: interpolate over the coset, keep len/blowup coefficients in reverse order, commit to them."""

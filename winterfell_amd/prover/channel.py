@@ -109,6 +109,18 @@ class ProverChannel:
         self.fri_alphas.append(a)
         return a
 
+    # the same two calls for ALL the FRI layers with the coin on the device (FriProver.build_layers' fused loop)
+    def fri_device_coin(self):
+        """the public coin, handed to the device for the layer loop; None when the hasher does not suit (hash.py DEVICE_COIN)"""
+        return self.public_coin.to_device() if self.hasher.DEVICE_COIN else None
+
+    def absorb_fri_layers(self, device_coin, roots, alphas):
+        """what commit_fri_layer / draw_fri_alpha would have recorded layer by layer, then the coin back on the host"""
+        for root, alpha in zip(roots, alphas):
+            self.commitments.append(np.array(root, copy=True))
+            self.fri_alphas.append(np.array(alpha, copy=True))
+        self.public_coin.take_back(device_coin)
+
     # ---- query phase (channel.rs:146-185)
     def grind_query_seed(self):
         self.pow_seed = np.array(self.public_coin.seed, copy=True)
