@@ -1,4 +1,5 @@
-// BLAKE3 (default mode, 32-byte output) for gfx950, one hash per lane.
+// BLAKE3 (default mode, 32-byte output) for gfx950, one hash per lane (and, for dependent chains of single-block hashes,
+// one hash per four lanes: quad_hash_block).
 //
 // Stands behind crypto::hash::Blake3_256 (crypto/src/hash/blake/mod.rs:24-66); the reference delegates the
 // arithmetic to the `blake3` crate, this is an independent implementation from the BLAKE3 specification.
@@ -83,6 +84,62 @@ __device__ __forceinline__ void merge(const uint32_t (&two)[16], uint32_t (&out)
 #pragma unroll
     for (int i = 0; i < 8; i++) cv[i] = iv(i);
     compress(cv, two, 0, 64, CHUNK_START | CHUNK_END | ROOT, out);
+}
+
+// ---- one single-block hash on FOUR adjacent lanes ---------------------------------------------------------------------------
+// The thin upper levels of a Merkle tree (and a coin step) are a chain of dependent compressions with few of them side by
+// side: one lane per compression leaves the chain ~800 instructions long per level.  Here lane q = lane & 3 of a quad owns
+// column q of the 4x4 state: the four G of a half-round run in the four lanes at once, the diagonal half-round rotates
+// rows b, c, d by 1, 2, 3 lanes with quad_perm DPP moves and back.  ~300 instructions per lane and compression.
+// The message (16 words) sits in LDS; each lane reads its four words of a round at offsets fixed by (round, q).
+struct Quad {
+    uint32_t off[7];        // per round: the byte offsets of m[s(2q)], m[s(2q+1)], m[s(8+2q)], m[s(9+2q)], 8 bits each
+    uint32_t a0, b0, d0;    // the lane's column of the initial state for cv = IV: IV[q] (rows a and c), IV[4+q], {0, 0, block_len, flags}[q]
+};
+
+__host__ __device__ constexpr uint32_t quad_offsets(int r, int q) {
+    return (uint32_t)(sched(r, 2 * q) * 4) | ((uint32_t)(sched(r, 2 * q + 1) * 4) << 8) | ((uint32_t)(sched(r, 8 + 2 * q) * 4) << 16) |
+           ((uint32_t)(sched(r, 9 + 2 * q) * 4) << 24);
+}
+
+__device__ __forceinline__ Quad quad_init(uint32_t q, uint32_t block_len, uint32_t flags) {
+    Quad k;
+#pragma unroll
+    for (int r = 0; r < 7; r++)
+        k.off[r] = q == 0 ? quad_offsets(r, 0) : q == 1 ? quad_offsets(r, 1) : q == 2 ? quad_offsets(r, 2) : quad_offsets(r, 3);
+    k.a0 = q == 0 ? iv(0) : q == 1 ? iv(1) : q == 2 ? iv(2) : iv(3);
+    k.b0 = q == 0 ? iv(4) : q == 1 ? iv(5) : q == 2 ? iv(6) : iv(7);
+    k.d0 = q < 2 ? 0u : q == 2 ? block_len : flags;
+    return k;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+
+// msg: the 16 message words in LDS (all four lanes pass the same pointer).  The lane gets output words q (lo) and 4 + q (hi).
+__device__ __forceinline__ void quad_hash_block(const Quad &k, const uint32_t *msg, uint32_t &lo, uint32_t &hi) {
+    uint32_t a = k.a0, b = k.b0, c = k.a0, d = k.d0;
+    const char *base = reinterpret_cast<const char *>(msg);
+#pragma unroll
+    for (int r = 0; r < 7; r++) {
+        const uint32_t t = k.off[r];
+        const uint32_t m0 = *reinterpret_cast<const uint32_t *>(base + (t & 0xff));
+        const uint32_t m1 = *reinterpret_cast<const uint32_t *>(base + ((t >> 8) & 0xff));
+        const uint32_t m2 = *reinterpret_cast<const uint32_t *>(base + ((t >> 16) & 0xff));
+        const uint32_t m3 = *reinterpret_cast<const uint32_t *>(base + (t >> 24));
+        B3_G(a, b, c, d, m0, m1);
+        b = quad_perm<0x39>(b);      // [1,2,3,0]: lane q takes row b from lane q + 1
+        c = quad_perm<0x4E>(c);      // [2,3,0,1]
+        d = quad_perm<0x93>(d);      // [3,0,1,2]
+        B3_G(a, b, c, d, m2, m3);
+        b = quad_perm<0x93>(b);      // and back
+        c = quad_perm<0x4E>(c);
+        d = quad_perm<0x39>(d);
+    }
+    lo = a ^ c;
+    hi = b ^ d;
 }
 
 // One chunk (<= 256 words): returns either the root hash (root = true) or the chunk's chaining value.

@@ -1,0 +1,226 @@
+// crypto::DefaultRandomCoin with its state in device memory (crypto/src/random/default.rs): wf_coin_* of the C ABI.
+#include "hashers.cuh"
+
+namespace {
+
+// ---- crypto::DefaultRandomCoin with its state in device memory (crypto/src/random/default.rs) -------------------------------
+// One lane: every step of the coin is one small hash that depends on the previous one.  What this buys is that a chain of
+// commit -> reseed -> draw -> use (the FRI layers) is queued on the stream without a host round trip per link.
+struct CoinState {
+    uint32_t seed[8];
+    uint64_t counter;
+    uint32_t failed;     // a draw ran out of its 1000 tries (default.rs:185-199: FailedToDrawFieldElement)
+    uint32_t pad;
+};
+static_assert(sizeof(CoinState) <= WF_COIN_BYTES, "WF_COIN_BYTES");
+
+// reseed (default.rs:150-153): seed = merge(seed, data), counter = 0; the digest is also copied to root_out when given
+template <class H>
+__global__ void coin_reseed_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out) {
+    uint32_t m[16], d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        m[i] = c->seed[i];
+        m[8 + i] = digest[i];
+    }
+    H::merge(m, d);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c->seed[i] = d[i];
+        if (root_out) root_out[i] = digest[i];
+    }
+    c->counter = 0;
+}
+
+// E::from_random_bytes over the first ELEMENT_BYTES of as_bytes: every base element must already be canonical
+template <int FIELD, int D>
+__device__ __forceinline__ bool coin_element(const uint32_t (&b)[8], uint64_t *out) {
+    if constexpr (FIELD == WF_FIELD_F128) {
+        uint64_t w[2 * D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const f128::u128 v = f128::join(b[4 * d], b[4 * d + 1], b[4 * d + 2], b[4 * d + 3]);
+            if (v >= f128::modulus()) return false;
+            w[2 * d] = (uint64_t)v;
+            w[2 * d + 1] = (uint64_t)(v >> 64);
+        }
+#pragma unroll
+        for (int i = 0; i < 2 * D; i++) out[i] = w[i];
+    } else {
+        uint64_t w[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            const uint64_t v = (uint64_t)b[2 * d] | ((uint64_t)b[2 * d + 1] << 32);
+            if constexpr (FIELD == WF_FIELD_F64) {
+                if (v >= gl::P) return false;
+                w[d] = gl::mul(v, 0xfffffffe00000001ull);   // BaseElement::new: times R^2 = 2^128 mod p
+            } else {
+                if (v >= f62::M) return false;
+                w[d] = rp62::to_mont(v);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) out[d] = w[d];
+    }
+    return true;
+}
+
+// draw::<E>() `count` times (default.rs:185-199): next() = merge_with_int(seed, ++counter) until the bytes decode
+template <class H, int FIELD, int D>
+__global__ void coin_draw_kernel(CoinState *c, uint32_t count, uint64_t *out) {
+    constexpr int WORDS = (FIELD == WF_FIELD_F128 ? 2 : 1) * D;
+    uint32_t seed[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) seed[i] = c->seed[i];
+    uint64_t counter = c->counter;
+    for (uint32_t k = 0; k < count; k++) {
+        bool ok = false;
+        for (int tries = 0; tries < 1000 && !ok; tries++) {
+            uint32_t d[8], b[8];
+            counter++;
+            H::merge_with_int(seed, counter, d);
+            H::as_bytes(d, b);
+            ok = coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS);
+        }
+        if (!ok) {
+            c->failed = 1;
+            break;
+        }
+    }
+    c->counter = counter;
+}
+
+// commit_fri_layer + draw_fri_alpha in one launch: reseed with `digest`, then one draw
+template <class H, int FIELD, int D>
+__global__ void coin_reseed_draw_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out, uint64_t *out) {
+    uint32_t m[16], seed[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        m[i] = c->seed[i];
+        m[8 + i] = digest[i];
+    }
+    H::merge(m, seed);
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        c->seed[i] = seed[i];
+        if (root_out) root_out[i] = digest[i];
+    }
+    uint64_t counter = 0;
+    bool ok = false;
+    for (int tries = 0; tries < 1000 && !ok; tries++) {
+        uint32_t d[8], b[8];
+        counter++;
+        H::merge_with_int(seed, counter, d);
+        H::as_bytes(d, b);
+        ok = coin_element<FIELD, D>(b, out);
+    }
+    if (!ok) c->failed = 1;
+    c->counter = counter;
+}
+
+template <class H>
+int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, const uint32_t *dg, uint32_t *cp, uint64_t *o) {
+#define WF_RD(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_kernel<H, FIELD, DEG>), dim3(1), dim3(1), 0, ctx->stream, c, dg, cp, o)
+    if (field == WF_FIELD_F128) {
+        if (D == 1) WF_RD(WF_FIELD_F128, 1);
+        else WF_RD(WF_FIELD_F128, 2);
+    } else if (field == WF_FIELD_F64) {
+        if (D == 1) WF_RD(WF_FIELD_F64, 1);
+        else if (D == 2) WF_RD(WF_FIELD_F64, 2);
+        else WF_RD(WF_FIELD_F64, 3);
+    } else {
+        if (D == 1) WF_RD(WF_FIELD_F62, 1);
+        else if (D == 2) WF_RD(WF_FIELD_F62, 2);
+        else WF_RD(WF_FIELD_F62, 3);
+    }
+#undef WF_RD
+    return WF_OK;
+}
+
+template <class H>
+int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t count, uint64_t *o) {
+#define WF_DRAW(FIELD, DEG) hipLaunchKernelGGL((coin_draw_kernel<H, FIELD, DEG>), dim3(1), dim3(1), 0, ctx->stream, c, count, o)
+    if (field == WF_FIELD_F128) {
+        if (D == 1) WF_DRAW(WF_FIELD_F128, 1);
+        else WF_DRAW(WF_FIELD_F128, 2);
+    } else if (field == WF_FIELD_F64) {
+        if (D == 1) WF_DRAW(WF_FIELD_F64, 1);
+        else if (D == 2) WF_DRAW(WF_FIELD_F64, 2);
+        else WF_DRAW(WF_FIELD_F64, 3);
+    } else {
+        if (D == 1) WF_DRAW(WF_FIELD_F62, 1);
+        else if (D == 2) WF_DRAW(WF_FIELD_F62, 2);
+        else WF_DRAW(WF_FIELD_F62, 3);
+    }
+#undef WF_DRAW
+    return WF_OK;
+}
+
+
+}  // namespace
+
+extern "C" int wf_coin_init(wf_ctx *ctx, void *d_coin, const void *h_seed) {
+    if (!ctx || !d_coin || !h_seed) return WF_ERR_INVALID_ARG;
+    CoinState st;
+    memset(&st, 0, sizeof(st));
+    memcpy(st.seed, h_seed, 32);
+    uint8_t image[WF_COIN_BYTES] = {0};
+    memcpy(image, &st, sizeof(st));
+    WF_HIP(hipMemcpyAsync(d_coin, image, WF_COIN_BYTES, hipMemcpyHostToDevice, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));    // `image` is on this frame
+    return WF_OK;
+}
+
+extern "C" int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d_digest, void *d_digest_copy) {
+    if (!ctx || !d_coin || !d_digest) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    wf_prof_begin(ctx, "coin");
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        hipLaunchKernelGGL(coin_reseed_kernel<decltype(h)>, dim3(1), dim3(1), 0, ctx->stream, (CoinState *)d_coin, (const uint32_t *)d_digest,
+                           (uint32_t *)d_digest_copy);
+        return (int)WF_OK;
+    }));
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+extern "C" int wf_coin_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, uint32_t count, void *d_out) {
+    if (!ctx || !d_coin || !d_out) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    const uint32_t max_ext = field == WF_FIELD_F128 ? 2 : 3;       // 32 digest bytes hold two f128 or three 64-bit elements
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
+    if (ext_degree < 1 || ext_degree > max_ext) return WF_ERR_UNSUPPORTED;
+    if (count == 0) return WF_OK;
+    wf_prof_begin(ctx, "coin");
+    WF_TRY(with_hasher(hash, [&](auto h) { return launch_coin_draw<decltype(h)>(ctx, field, ext_degree, (CoinState *)d_coin, count, (uint64_t *)d_out); }));
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+extern "C" int wf_coin_reseed_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, const void *d_digest, void *d_digest_copy,
+                                  void *d_out) {
+    if (!ctx || !d_coin || !d_digest || !d_out) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
+    if (ext_degree < 1 || ext_degree > (field == WF_FIELD_F128 ? 2u : 3u)) return WF_ERR_UNSUPPORTED;
+    wf_prof_begin(ctx, "coin");
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        return launch_coin_reseed_draw<decltype(h)>(ctx, field, ext_degree, (CoinState *)d_coin, (const uint32_t *)d_digest, (uint32_t *)d_digest_copy,
+                                                    (uint64_t *)d_out);
+    }));
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+extern "C" int wf_coin_read(wf_ctx *ctx, const void *d_coin, void *h_seed, uint64_t *h_counter) {
+    if (!ctx || !d_coin || !h_seed || !h_counter) return WF_ERR_INVALID_ARG;
+    CoinState st;
+    WF_HIP(hipMemcpyAsync(&st, d_coin, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
+    WF_HIP(hipStreamSynchronize(ctx->stream));
+    memcpy(h_seed, st.seed, 32);
+    *h_counter = st.counter;
+    return st.failed ? WF_ERR_NOT_FOUND : WF_OK;
+}

@@ -1,0 +1,156 @@
+// FRI layer commit, first half: transpose_slice + hash of every row in one pass (fri/src/prover/mod.rs:321-336).
+#include "hashers.cuh"
+
+namespace {
+
+// FRI layer commit, first half, in one pass (fri/src/prover/mod.rs:321-336 = transpose_slice + hash each row):
+//   tr[i][j] = ev[i + j * rc]   and   leaf_i = H::hash_elements(tr[i]).
+// A workgroup takes R consecutive rows: the N strided runs of R elements are read coalesced into an LDS tile
+// [R][row_words + 1], every lane hashes its row straight out of the tile, and the tile is written to the transposed matrix
+// as ONE contiguous block.  (The separate transpose wrote 8 or 16 bytes per lane at a row-sized stride — 1 TB/s — and the
+// row hash then read the matrix back.)  EW = 64-bit words per element (ext_degree * words per base element).
+template <class H, int MODE>
+__global__ __launch_bounds__(256) void fri_rows_kernel(const uint64_t *ev, uint64_t rc, uint32_t N, uint32_t EW, uint32_t R, uint64_t *tr,
+                                                       void *leaves) {
+    extern __shared__ uint64_t fri_tile[];
+    const uint32_t row_words = N * EW, pitch = row_words + 1;
+    const uint64_t r0 = (uint64_t)blockIdx.x * R;
+    const uint32_t nr = rc - r0 < R ? (uint32_t)(rc - r0) : R;
+    const uint32_t run = nr * EW;                        // consecutive words of one strided run
+    for (uint32_t idx = threadIdx.x; idx < N * run; idx += 256) {
+        const uint32_t j = idx / run, k = idx - j * run;
+        fri_tile[(k / EW) * pitch + j * EW + (k % EW)] = ev[(r0 + (uint64_t)j * rc) * EW + k];
+    }
+    __syncthreads();
+    for (uint32_t t = threadIdx.x; t < nr; t += 256) {
+        uint32_t d[8];
+        H::template hash_elems<MODE, false>(fri_tile + t * pitch, row_words, d);
+        store_digest(leaves, r0 + t, d);
+    }
+    for (uint32_t idx = threadIdx.x; idx < nr * row_words; idx += 256) {
+        const uint32_t r = idx / row_words, w = idx - r * row_words;
+        tr[r0 * row_words + idx] = fri_tile[r * pitch + w];
+    }
+}
+
+// The same for rows of at most 128 bytes, the shapes the folding factors 2..16 give over f64 / f128 and their extensions:
+// every lane owns one row.  Its N elements are N loads that are coalesced across the lanes as they stand (lane-consecutive
+// rows are consecutive in each strided run), the row is hashed out of registers, and only the transposed copy goes through LDS —
+// per wavefront, 64 rows = one contiguous block of the output, written back 16 bytes per lane in address order.  Against the
+// tile kernel above: no index arithmetic with run-time divisors (it was ~40 % of the instructions), 16-byte accesses.
+template <class H, int MODE, int N, int EW>
+__global__ __launch_bounds__(256) void fri_rows_direct_kernel(const uint64_t *ev, uint64_t rc, uint64_t *tr, void *leaves) {
+    constexpr int RW = N * EW, CP = RW / 2;                      // 64-bit words / 16-byte chunks per row
+    constexpr bool POW2 = (CP & (CP - 1)) == 0;
+    constexpr int SPREAD = POW2 && CP < 16 ? 16 / CP : 1;        // rows that share a swizzle value: 16 lanes then touch 16 banks-of-16-bytes
+    __shared__ uint4 stage[4][64 * CP];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t wave_row0 = (uint64_t)blockIdx.x * 256 + wave * 64;
+    const uint64_t r = wave_row0 + lane;
+    auto swz = [&](uint32_t row) -> uint32_t { return POW2 ? ((row / SPREAD) & (CP - 1)) : 0u; };
+    uint64_t w[RW];
+#pragma unroll
+    for (int i = 0; i < RW; i++) w[i] = 0;
+    if (r < rc) {
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const uint64_t *e = ev + (r + (uint64_t)j * rc) * EW;
+            if constexpr (EW % 2 == 0) {
+#pragma unroll
+                for (int k = 0; k < EW / 2; k++) {
+                    const uint4 v = reinterpret_cast<const uint4 *>(e)[k];
+                    w[j * EW + 2 * k] = (uint64_t)v.x | ((uint64_t)v.y << 32);
+                    w[j * EW + 2 * k + 1] = (uint64_t)v.z | ((uint64_t)v.w << 32);
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < EW; k++) w[j * EW + k] = e[k];
+            }
+        }
+        uint32_t d[8];
+        H::template hash_elems<MODE, false>(w, RW, d);
+        store_digest(leaves, r, d);
+    }
+    uint4 *st = stage[wave];
+#pragma unroll
+    for (int c = 0; c < CP; c++)
+        st[lane * CP + (c ^ swz(lane))] = make_uint4((uint32_t)w[2 * c], (uint32_t)(w[2 * c] >> 32), (uint32_t)w[2 * c + 1], (uint32_t)(w[2 * c + 1] >> 32));
+    __syncthreads();
+    if (wave_row0 >= rc) return;
+    const uint32_t nv = rc - wave_row0 < 64 ? (uint32_t)(rc - wave_row0) : 64u;
+    uint4 *out = reinterpret_cast<uint4 *>(tr + wave_row0 * RW);
+#pragma unroll
+    for (int i = 0; i < CP; i++) {
+        const uint32_t L = i * 64 + lane, row = L / CP, cc = L % CP;
+        if (row < nv) out[L] = st[row * CP + (cc ^ swz(row))];
+    }
+}
+
+template <class H, int MODE, int N, int EW>
+void launch_fri_rows_direct(wf_ctx *ctx, const uint64_t *ev, uint64_t rc, uint64_t *tr, void *leaves) {
+    hipLaunchKernelGGL((fri_rows_direct_kernel<H, MODE, N, EW>), dim3((uint32_t)((rc + 255) / 256)), dim3(256), 0, ctx->stream, ev, rc, tr, leaves);
+}
+
+// the (mode, N, EW) shapes with a direct kernel; false = take the tile kernel
+template <class H>
+bool try_fri_rows_direct(wf_ctx *ctx, int mode, const uint64_t *ev, uint64_t rc, uint32_t N, uint32_t EW, uint64_t *tr, void *leaves) {
+    if constexpr (!H::WAVE_TREE) {
+        return false;     // the BLAKE3 family only: for the others the hash, not the data movement, is the time
+    } else {
+        if ((rc + 255) / 256 > 0x7fffffffull) return false;
+#define WF_FD(M, NN, E) if (mode == M && N == NN && EW == E) { launch_fri_rows_direct<H, M, NN, E>(ctx, ev, rc, tr, leaves); return true; }
+        WF_FD(MODE_F64_CANON, 2, 1) WF_FD(MODE_F64_CANON, 4, 1) WF_FD(MODE_F64_CANON, 8, 1) WF_FD(MODE_F64_CANON, 16, 1)
+        WF_FD(MODE_F64_CANON, 2, 2) WF_FD(MODE_F64_CANON, 4, 2) WF_FD(MODE_F64_CANON, 8, 2)
+        WF_FD(MODE_F64_CANON, 2, 3) WF_FD(MODE_F64_CANON, 4, 3)
+        WF_FD(MODE_RAW, 2, 2) WF_FD(MODE_RAW, 4, 2) WF_FD(MODE_RAW, 8, 2) WF_FD(MODE_RAW, 2, 4) WF_FD(MODE_RAW, 4, 4)
+#undef WF_FD
+        return false;
+    }
+}
+
+template <class H>
+int launch_fri_rows(wf_ctx *ctx, int mode, const uint64_t *ev, uint64_t rc, uint32_t N, uint32_t EW, uint64_t *tr, void *leaves) {
+    wf_prof_begin(ctx, "fri_transpose_hash");
+    if (!try_fri_rows_direct<H>(ctx, mode, ev, rc, N, EW, tr, leaves)) {
+        const uint32_t pitch = N * EW + 1;
+        uint32_t R = 256;
+        while (R > 32 && (size_t)R * pitch * 8 > 40960) R >>= 1;
+        const uint64_t blocks = (rc + R - 1) / R;
+        if (blocks > 0x7fffffffull) {
+            wf_prof_end(ctx);
+            return WF_ERR_DOMAIN_TOO_LARGE;
+        }
+        const size_t lds = (size_t)R * pitch * 8;
+#define WF_FR(MODE) hipLaunchKernelGGL((fri_rows_kernel<H, MODE>), dim3((uint32_t)blocks), dim3(256), lds, ctx->stream, ev, rc, N, EW, R, tr, leaves)
+        switch (mode) {
+            case MODE_F64_CANON: WF_FR(MODE_F64_CANON); break;
+            case MODE_F62_CANON: WF_FR(MODE_F62_CANON); break;
+            default: WF_FR(MODE_RAW); break;
+        }
+#undef WF_FR
+    }
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+
+}  // namespace
+
+// used by wf_fri_layer_commit (fri.hip): *done = 0 when the caller should take the unfused path (small Rescue layers, where the
+// lane-cooperative row hash wins)
+int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
+                          void *d_transposed, void *d_leaves, int *done) {
+    *done = 0;
+    WF_TRY(check_hash(hash));
+    if (field != WF_FIELD_F64 && (hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256)) return WF_ERR_UNSUPPORTED;
+    if (field != WF_FIELD_F62 && hash == WF_HASH_RP62_248) return WF_ERR_UNSUPPORTED;
+    const uint64_t rc = 1ull << log_rc;
+    const bool rescue = hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256 || hash == WF_HASH_RP62_248;
+    if (rescue && rc <= rcoop::COOP_MAX) return WF_OK;
+    const int mode = field == WF_FIELD_F64 ? MODE_F64_CANON : (field == WF_FIELD_F62 ? MODE_F62_CANON : MODE_RAW);
+    const uint32_t EW = ext_degree * (field == WF_FIELD_F128 ? 2 : 1);
+    *done = 1;
+    return with_hasher(hash, [&](auto h) {
+        return launch_fri_rows<decltype(h)>(ctx, mode, (const uint64_t *)d_evals, rc, 1u << log_nf, EW, (uint64_t *)d_transposed, d_leaves);
+    });
+}
