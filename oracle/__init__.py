@@ -577,9 +577,12 @@ class GenericField:
         return out
 
     # ---- constraint evaluation (constraints_tmpl.inc) -----------------------------------------------------------
-    AIR_FIB_SMALL, AIR_RESCUE, AIR_FIB8, AIR_MULFIB2, AIR_MULFIB8, AIR_VDF, AIR_VDF_EXEMPT = 0, 1, 2, 3, 4, 5, 6
+    AIR_FIB_SMALL, AIR_RESCUE, AIR_FIB8, AIR_MULFIB2, AIR_MULFIB8, AIR_VDF, AIR_VDF_EXEMPT, AIR_RESCUE_RAPS = 0, 1, 2, 3, 4, 5, 6, 7
     # width, transition constraints, periodic columns, cycle
-    AIR_SHAPES = {0: (2, 2, 0, 0), 1: (4, 4, 9, 16), 2: (2, 2, 0, 0), 3: (2, 2, 0, 0), 4: (8, 8, 0, 0), 5: (1, 1, 0, 0), 6: (1, 1, 0, 0)}
+    AIR_SHAPES = {0: (2, 2, 0, 0), 1: (4, 4, 9, 16), 2: (2, 2, 0, 0), 3: (2, 2, 0, 0), 4: (8, 8, 0, 0), 5: (1, 1, 0, 0), 6: (1, 1, 0, 0),
+                  7: (8, 8, 10, 16)}
+    # auxiliary segment: width (columns of E), transition constraints, random elements
+    AIR_AUX_SHAPES = {7: (3, 3, 3)}
 
     def air_evaluate_transition(self, air, D, cur, nxt, periodic):
         """Air::evaluate_transition over degree-D elements; cur / nxt: width*D*W words, periodic: num_periodic*D*W."""
@@ -589,6 +592,16 @@ class GenericField:
         fn = self._fn("air_evaluate_transition")
         fn.restype = ctypes.c_int
         assert fn(ctypes.c_int(air), ctypes.c_uint(D), _ptr(c), _ptr(n_), _ptr(pv), _ptr(out)) == 0
+        return out
+
+    def air_evaluate_aux_transition(self, air, Dm, D, mcur, mnxt, acur, anxt, periodic, rand):
+        """Air::evaluate_aux_transition: main frame / periodic values over F (Dm components per element), aux frame / rand over E."""
+        _, nta, _ = self.AIR_AUX_SHAPES[air]
+        out = np.empty(nta * D * self.W, dtype=np.uint64)
+        a = [_u64arr(x) for x in (mcur, mnxt, acur, anxt, periodic, rand)]
+        fn = self._fn("air_evaluate_aux_transition")
+        fn.restype = ctypes.c_int
+        assert fn(ctypes.c_int(air), ctypes.c_uint(Dm), ctypes.c_uint(D), *[_ptr(x) for x in a], _ptr(out)) == 0
         return out
 
     def air_periodic_polys(self, air):
@@ -615,6 +628,44 @@ class GenericField:
         rc = fn(ctypes.c_int(air), _ptr(l), _u64(row_width), _u64(n), _u64(lde_blowup), _u64(ce_blowup), _ptr(po), ctypes.c_uint(D),
                 _ptr(t), _u64(len(assertions)), _ptr(cols), _ptr(steps), _ptr(vals), _ptr(b), _ptr(out))
         assert rc == 0
+        return out
+
+    def evaluate_constraints_full(self, air, lde, row_width, aux_lde, aux_row_width, n, lde_blowup, ce_blowup, offset, D, cc_t, assertions,
+                                  cc_b, aux_assertions, cc_x, rand):
+        """the same for a trace with an auxiliary segment (evaluate_fragment_full): aux_lde (n*lde_blowup, aux_row_width*W) words,
+        rows of E elements; aux_assertions: (column, step, E value words); cc_t = main then aux coefficients; rand: E elements."""
+        l, x, t, b, cx, rd = (_u64arr(v) for v in (lde, aux_lde, cc_t, cc_b, cc_x, rand))
+        cols = np.array([a[0] for a in assertions], dtype=np.uint64)
+        steps = np.array([a[1] for a in assertions], dtype=np.uint64)
+        vals = np.concatenate([_u64arr(a[2]).reshape(-1) for a in assertions])
+        xcols = np.array([a[0] for a in aux_assertions], dtype=np.uint64)
+        xsteps = np.array([a[1] for a in aux_assertions], dtype=np.uint64)
+        xvals = np.concatenate([_u64arr(a[2]).reshape(-1) for a in aux_assertions])
+        po = self.pack([offset])
+        out = np.empty(n * ce_blowup * D * self.W, dtype=np.uint64)
+        fn = self._fn("evaluate_constraints_full")
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.c_int(air), _ptr(l), _u64(row_width), _ptr(x), _u64(aux_row_width), _u64(n), _u64(lde_blowup), _u64(ce_blowup), _ptr(po),
+                ctypes.c_uint(D), _ptr(t), _u64(len(assertions)), _ptr(cols), _ptr(steps), _ptr(vals), _ptr(b), _u64(len(aux_assertions)),
+                _ptr(xcols), _ptr(xsteps), _ptr(xvals), _ptr(cx), _ptr(rd), _ptr(out))
+        assert rc == 0, rc
+        return out
+
+    def rescue_raps_build_trace(self, seeds, permuted_seeds):
+        """f128 only: RescueRapsProver::build_trace; seeds / permuted_seeds: lists of [a, b] -> (8, 16*len(seeds)*W) words."""
+        assert self.name == "f128" and len(seeds) == len(permuted_seeds)
+        out = np.empty((8, 16 * len(seeds) * self.W), dtype=np.uint64)
+        ps, pp = self.pack([v for s_ in seeds for v in s_]), self.pack([v for s_ in permuted_seeds for v in s_])
+        self._fn("rescue_raps_build_trace")(_ptr(ps), _ptr(pp), _u64(len(seeds)), _ptr(out))
+        return out
+
+    def rescue_raps_build_aux(self, trace, D, rand):
+        """f128 only: RescueRapsProver::build_aux_trace; trace (8, n*W) words, rand: 3*D*W words -> (3, n*D*W) words."""
+        assert self.name == "f128"
+        tr, rd = _u64arr(trace), _u64arr(rand)
+        n = tr.size // (8 * self.W)
+        out = np.empty((3, n * D * self.W), dtype=np.uint64)
+        self._fn("rescue_raps_build_aux")(_ptr(tr), _u64(n), ctypes.c_uint(D), _ptr(rd), _ptr(out))
         return out
 
     def fib_small_build_trace(self, n):

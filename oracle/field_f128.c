@@ -55,6 +55,69 @@ void or_f128_rescue_build_trace(const u128 seed[2], uint64_t iterations, u128 *t
     }
 }
 
+/* RescueRapsProver::build_trace — examples/src/rescue_raps/prover.rs:36-94 (RapTraceTable::fill): two hash chains side by side,
+ * chain 0 absorbing seeds[k], chain 1 permuted_seeds[k] (both chain_length x 2 elements) at step 14 of every 16-step cycle.
+ * trace: 8 columns of n = chain_length * 16 elements, column-major. */
+void or_f128_rescue_raps_build_trace(const u128 *seeds, const u128 *permuted, uint64_t chain_length, u128 *trace) {
+    const uint64_t n = chain_length * 16;
+    u128 st[8] = {seeds[0], seeds[1], 0, 0, permuted[0], permuted[1], 0, 0};
+    for (uint64_t step = 0;; step++) {
+        for (int c = 0; c < 8; c++) trace[c * n + step] = st[c];
+        if (step + 1 == n) break;
+        if (step % 16 < 14) {                                  /* apply_rescue_round_parallel, mod.rs:184-190 */
+            rescue_apply_round(st, step);
+            rescue_apply_round(st + 4, step);
+        } else if (step % 16 == 14) {
+            const uint64_t idx = step / 16 + 1;
+            if (idx < chain_length) {
+                st[0] = f128_add(st[0], seeds[2 * idx]);
+                st[1] = f128_add(st[1], seeds[2 * idx + 1]);
+                st[4] = f128_add(st[4], permuted[2 * idx]);
+                st[5] = f128_add(st[5], permuted[2 * idx + 1]);
+            }
+        }
+    }
+}
+
+/* QuadExtension::inv (math/src/field/extensions/quadratic.rs:81-94): frobenius(x) / norm(x), frobenius = [x0 + x1, -x1] (mod.rs:280-282) */
+static void f128_extD_inv(unsigned D, const u128 *x, u128 *out) {
+    if (D == 1) { out[0] = f128_inv(x[0]); return; }
+    if (x[0] == 0 && x[1] == 0) { out[0] = out[1] = 0; return; }
+    const u128 num[2] = {f128_add(x[0], x[1]), f128_sub(0, x[1])};
+    u128 norm[2];
+    f128_ext2_mul(x, num, norm);
+    const u128 di = f128_inv(norm[0]);
+    out[0] = f128_mul(num[0], di);
+    out[1] = f128_mul(num[1], di);
+}
+
+/* RescueRapsProver::build_aux_trace — rescue_raps/prover.rs:157-205.  trace: the 8 main columns (column-major, n rows);
+ * rand: 3 elements of E (D components each); aux: 3 columns of n E elements, column-major (aux[(c * n + i) * D + d]). */
+void or_f128_rescue_raps_build_aux(const u128 *trace, uint64_t n, unsigned D, const u128 *rand, u128 *aux) {
+    u128 *a0 = aux, *a1 = aux + n * D, *a2 = aux + 2 * n * D;
+    memset(aux, 0, 3 * n * D * sizeof(u128));
+    u128 t[2], u[2], v[2], lift[2] = {0, 0};
+#define RAPS_COMBINE(dst, x0, x1)                                                                  \
+    lift[0] = (x0); or_f128_e_mul(D, rand, lift, u);                                                \
+    lift[0] = (x1); or_f128_e_mul(D, rand + D, lift, v);                                            \
+    or_f128_e_add(D, u, v, (dst));
+    RAPS_COMBINE(a0, trace[0], trace[n])                       /* row 0: alpha_0 * state[0] + alpha_1 * state[1] */
+    RAPS_COMBINE(a1, trace[4 * n], trace[5 * n])
+    a2[0] = 1;
+    for (uint64_t i = 1; i < n; i++) {
+        if (i % 16 == 14) {                                    /* the absorbed values = next - current on the rate registers */
+            RAPS_COMBINE(a0 + i * D, f128_sub(trace[i + 1], trace[i]), f128_sub(trace[n + i + 1], trace[n + i]))
+            RAPS_COMBINE(a1 + i * D, f128_sub(trace[4 * n + i + 1], trace[4 * n + i]), f128_sub(trace[5 * n + i + 1], trace[5 * n + i]))
+        }
+        or_f128_e_add(D, a0 + (i - 1) * D, rand + 2 * D, u);   /* num */
+        or_f128_e_add(D, a1 + (i - 1) * D, rand + 2 * D, v);   /* denom */
+        f128_extD_inv(D, v, t);
+        or_f128_e_mul(D, a2 + (i - 1) * D, u, v);
+        or_f128_e_mul(D, v, t, a2 + i * D);
+    }
+#undef RAPS_COMBINE
+}
+
 /* VdfProver::build_trace — examples/src/vdf/regular/prover.rs:30-41 and vdf/exempt/prover.rs:30-44 (exempt = 1: n - 1 real
  * states, then the garbage value 123 in the last row).  state' = (state - 42)^INV_ALPHA, INV_ALPHA = (2p - 1) / 3
  * (vdf/regular/mod.rs:30-32).  One column of n elements. */

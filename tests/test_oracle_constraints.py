@@ -136,3 +136,74 @@ def test_periodic_value_table_reference_example(oracle):
     for i in (0, 13, 14, 15, 16, 30, 47, 63):
         x = fld.exp(fld.exp(g, i), n // 16)
         assert fld.unpack(fld.evaluate_columns_at(polys[:1], 1, fld.pack([x]), 1, 1).reshape(-1))[0] == (1 if i % 16 < 14 else 0)
+
+
+# ---- RescueRapsAir: a trace with an auxiliary segment (examples/src/rescue_raps) ------------------------------------------------
+def _raps_case(oracle, n, D, seed, corrupt=None):
+    fld, offset = oracle.f128, 3
+    chain = n // 16
+    seeds = [[1000 + 2 * i, 77 * i + 5] for i in range(chain)]
+    permuted = seeds[2:] + seeds[:2]                                          # rescue_raps/mod.rs:83-85
+    trace = fld.rescue_raps_build_trace(seeds, permuted)
+    rand = _rand_e(fld, 3, D, seed + 2)
+    aux = fld.rescue_raps_build_aux(trace, D, fld.pack(sum(rand, [])))
+    if corrupt == "main":
+        trace = trace.copy()
+        trace[1, 5 * fld.W] ^= np.uint64(1)
+    if corrupt == "aux":
+        aux = aux.copy()
+        aux[2, 7 * D * fld.W] ^= np.uint64(1)
+    lde_blowup, ce_blowup, ncols = 8, 4, 3
+    polys, lde, _, _ = fld.build_trace_commitment(0, trace, lde_blowup, offset)
+    apolys, alde, _, _ = fld.build_trace_commitment(0, aux, lde_blowup, offset, D=D)
+    t = [fld.unpack(col) for col in trace]
+    last = n - 1
+    assertions = [(2, 0, 0), (3, 0, 0), (6, 0, 0), (7, 0, 0), (0, last, t[0][last]), (1, last, t[1][last]), (4, last, t[4][last]), (5, last, t[5][last])]
+    one_e = [1] + [0] * (D - 1)
+    aux_assertions = [(2, 0, one_e), (2, last, one_e)]                        # get_aux_assertions, air.rs:236-239
+    cc_t, cc_b, cc_x = _rand_e(fld, 8 + 3, D, seed), _rand_e(fld, 8, D, seed + 1), _rand_e(fld, 2, D, seed + 3)
+    out = fld.evaluate_constraints_full(fld.AIR_RESCUE_RAPS, lde, lde.shape[1] // fld.W, alde, alde.shape[1] // fld.W, n, lde_blowup, ce_blowup,
+                                        offset, D, fld.pack(sum(cc_t, [])), [(c, s, fld.pack([v])) for c, s, v in assertions], fld.pack(sum(cc_b, [])),
+                                        [(c, s, fld.pack(v)) for c, s, v in aux_assertions], fld.pack(sum(cc_x, [])), fld.pack(sum(rand, [])))
+    return dict(fld=fld, offset=offset, n=n, D=D, ce_blowup=ce_blowup, ncols=ncols, out=out, polys=polys, apolys=apolys, rand=rand, cc_t=cc_t,
+                cc_b=cc_b, cc_x=cc_x, assertions=assertions, aux_assertions=aux_assertions, aux=aux)
+
+
+@pytest.mark.parametrize("n,D", [(64, 1), (64, 2), (128, 2)])
+def test_aux_segment_evaluation_matches_verifier_formula(oracle, n, D):
+    """evaluate_fragment_full (main + auxiliary transition constraints under one divisor, main + aux assertions per boundary
+    group) against the verifier's out-of-domain equation with the aux frame, for the RAP example."""
+    c = _raps_case(oracle, n, D, 31 * n + D)
+    fld, E = c["fld"], Ext(c["fld"], D)
+    E.one = 1
+    assert fld.unpack(c["aux"][2])[-D:] == [1] + [0] * (D - 1)                # the permutation argument closes: last cell = 1
+    co = _composition_coeffs(c)
+    assert not co[c["ncols"] * n:].any() and co[(c["ncols"] - 1) * n:c["ncols"] * n].any()
+    rng = np.random.default_rng(9)
+    z = [int(rng.integers(1, 2**62)) for _ in range(D)]
+    g = fld.root_of_unity(n.bit_length() - 1)
+    zw, zgw = fld.pack(z), fld.pack(E.mul(z, E.lift(g)))
+    cur, nxt = fld.evaluate_columns_at(c["polys"], 8, zw, D, 1), fld.evaluate_columns_at(c["polys"], 8, zgw, D, 1)
+    acur, anxt = fld.evaluate_columns_at(c["apolys"], 3, zw, D, D), fld.evaluate_columns_at(c["apolys"], 3, zgw, D, D)
+    zc = E.pow(z, n // 16)
+    per = fld.evaluate_columns_at(fld.air_periodic_polys(fld.AIR_RESCUE_RAPS), 10, fld.pack(zc), D, 1).reshape(-1)
+    tev = fld.unpack(fld.air_evaluate_transition(fld.AIR_RESCUE_RAPS, D, cur.reshape(-1), nxt.reshape(-1), per))
+    aev = fld.unpack(fld.air_evaluate_aux_transition(fld.AIR_RESCUE_RAPS, D, D, cur.reshape(-1), nxt.reshape(-1), acur.reshape(-1), anxt.reshape(-1),
+                                                     per, fld.pack(sum(c["rand"], []))))
+    evals = [tev[k * D:(k + 1) * D] for k in range(8)] + [aev[k * D:(k + 1) * D] for k in range(3)]
+    row = fld.unpack(cur.reshape(-1)) + fld.unpack(acur.reshape(-1))
+    ood_cur = [row[k * D:(k + 1) * D] for k in range(11)]
+    # aux assertions address column 8 + c of the joint row; their values are E elements: subtract them up front
+    assertions = list(c["assertions"])
+    for col, step, val in c["aux_assertions"]:
+        ood_cur.append(E.sub(ood_cur[8 + col], val))
+        assertions.append((len(ood_cur) - 1, step, 0))
+    H = E.horner([fld.unpack(r) for r in co], z)
+    assert ood_constraint_equation_holds(E, 1, g, n, z, H, evals, c["cc_t"], ood_cur, assertions, c["cc_b"] + c["cc_x"])
+
+
+@pytest.mark.parametrize("where", ["main", "aux"])
+def test_aux_segment_invalid_trace_breaks_divisibility(oracle, where):
+    c = _raps_case(oracle, 64, 2, 4, corrupt=where)
+    co = _composition_coeffs(c)
+    assert co[c["ncols"] * 64:].any()
