@@ -254,7 +254,9 @@ enum {
     WF_AIR_MULFIB2 = 3,     /* examples/src/fibonacci/mulfib2/air.rs (2 columns, degree-2 constraints, ce_blowup 2)   */
     WF_AIR_MULFIB8 = 4,     /* examples/src/fibonacci/mulfib8/air.rs (8 columns, degree 2, ce_blowup 2)               */
     WF_AIR_VDF = 5,         /* examples/src/vdf/regular/air.rs (1 column, degree 3, ce_blowup 2)                      */
-    WF_AIR_VDF_EXEMPT = 6   /* examples/src/vdf/exempt/air.rs (the same with 2 transition exemptions)                 */
+    WF_AIR_VDF_EXEMPT = 6,  /* examples/src/vdf/exempt/air.rs (the same with 2 transition exemptions)                 */
+    WF_AIR_RESCUE_RAPS = 7  /* examples/src/rescue_raps/air.rs (8 + 3 auxiliary columns, 10 periodic columns, f128 only;
+                               wf_evaluate_constraints_aux)                                                            */
 };
 
 /* DefaultConstraintEvaluator::evaluate for a single-segment trace (prover/src/constraints/evaluator/default.rs:52-106,
@@ -274,6 +276,23 @@ int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree
                             const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
                             const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
                             void *d_out);
+
+/* The same for a trace with an auxiliary segment (TraceInfo::is_multi_segment): evaluate_fragment_full
+ * (evaluator/default.rs:214-271) = the main transition constraints as above plus Air::evaluate_aux_transition over the
+ * main frame, the auxiliary frame (rows of the device-resident row-major LDE of the aux segment: aux_row_width base
+ * elements per row, the segment's columns first, ext_degree words each) and the segment's random elements
+ * (AuxRandElements: h_aux_rand_elements, elements of E), merged under the one transition divisor with the coefficients
+ * h_cc_transition = [main constraints..., aux constraints...] (coefficient times evaluation over E, default.rs:325-331);
+ * BoundaryConstraints::evaluate_all (boundary.rs:103-115): an assertion against the aux segment (column, step, value in
+ * E, coefficient) joins the boundary group of its step (boundary.rs:58-73).  Built in: WF_AIR_RESCUE_RAPS. */
+int wf_evaluate_constraints_aux(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_main_lde, uint64_t main_row_width,
+                                const void *d_aux_lde, uint64_t aux_row_width, uint32_t log_n, uint32_t log_lde_blowup,
+                                uint32_t log_ce_blowup, const void *h_domain_offset, const void *h_cc_transition,
+                                uint32_t num_assertions, const uint32_t *h_assert_columns, const uint64_t *h_assert_steps,
+                                const void *h_assert_values, const void *h_cc_boundary, uint32_t num_aux_assertions,
+                                const uint32_t *h_aux_assert_columns, const uint64_t *h_aux_assert_steps,
+                                const void *h_aux_assert_values, const void *h_cc_aux_boundary, const void *h_aux_rand_elements,
+                                void *d_out);
 
 /* ---- prover::composer (DEEP composition) and out-of-domain frames ------------------------------------- */
 /* ColMatrix::evaluate_columns_at for one or more points (prover/src/matrix/col_matrix.rs; polynom::eval,

@@ -165,6 +165,20 @@ def example(name, fld, n):
         seed, result = [t0[0], t1[0]], [t0[n - 1], t1[n - 1]]
         return dict(air=1, width=4, degrees=[(3, (16,))] * 4, trace=trace,
                     assertions=[(0, 0, seed[0]), (1, 0, seed[1]), (0, n - 1, result[0]), (1, n - 1, result[1])], pub=seed + result, exemptions=1)
+    if name == "rescue_raps":                                               # examples/src/rescue_raps: f128, 8 + 3 auxiliary columns
+        assert fld.name == "f128"
+        chain = n // 16
+        seeds = [[1000 + 2 * i, 77 * i + 5] for i in range(chain)]         # the example draws them at random (mod.rs:79-81)
+        permuted = seeds[2:] + seeds[:2]                                    # mod.rs:83-85
+        trace = fld.rescue_raps_build_trace(seeds, permuted)
+        t = [fld.unpack(col) for col in trace]
+        last = n - 1
+        result = [t[0][last], t[1][last], t[4][last], t[5][last]]           # PublicInputs::to_elements: flatten(result), air.rs:49-53
+        assertions = [(2, 0, 0), (3, 0, 0), (6, 0, 0), (7, 0, 0), (0, last, result[0]), (1, last, result[1]), (4, last, result[2]), (5, last, result[3])]
+        aux = dict(width=3, num_rands=3, degrees=[(1, (16,)), (1, (16,)), (2, ())],                       # air.rs:72-76
+                   assertions=[(2, 0, 1), (2, last, 1)],                                                   # get_aux_assertions: E::ONE, air.rs:236-239
+                   build=lambda D, rand: fld.rescue_raps_build_aux(trace, D, rand))
+        return dict(air=7, width=8, degrees=[(3, (16,))] * 8, trace=trace, assertions=assertions, pub=result, exemptions=1, aux=aux)
     raise ValueError(name)
 
 
@@ -177,24 +191,45 @@ def prove(name, fld, hasher_id, n, options):
     ew = D * W
     width, degrees = ex["width"], ex["degrees"]
     nt, na = len(degrees), len(ex["assertions"])
-    ce_blowup = max(_min_blowup(*d) for d in degrees)
-    highest = max(_degree_eval(bs, cy, n) for bs, cy in degrees)
+    aux = ex.get("aux")                                                      # the auxiliary trace segment, if the AIR has one
+    aw, nr = (aux["width"], aux["num_rands"]) if aux else (0, 0)
+    nta, nxa = (len(aux["degrees"]), len(aux["assertions"])) if aux else (0, 0)
+    all_degrees = degrees + (aux["degrees"] if aux else [])
+    ce_blowup = max(_min_blowup(*d) for d in all_degrees)
+    highest = max(_degree_eval(bs, cy, n) for bs, cy in all_degrees)
     ncols = max(-(-(highest - (n - ex["exemptions"]) + 1) // n), 1)         # AirContext::num_constraint_composition_columns
     offset = to_internal(fld, {"f64t": 7, "f128": 3}[fld.name])             # StarkField::GENERATOR
     # 0. channel: seed the coin with context + public inputs (channel.rs:57-75)
-    ctx_elems = context_to_elements(fld.M, 8 * W, width, n, na + nt, options)
+    ctx_elems = context_to_elements(fld.M, 8 * W, width, n, na + nt + nta + nxa, options, aux_width=aw, num_aux_rands=nr)
     coin = Coin(h, fld.pack([to_internal(fld, v) for v in ctx_elems] + list(ex["pub"])))
     art = {"context_elements": ctx_elems, "pub_inputs": list(ex["pub"]), "coin_seed": coin.seed.copy()}
     # 1. commit to the main trace segment
     polys, lde, leaves, nodes = fld.build_trace_commitment(hasher_id, ex["trace"], b, offset)
     trace_root = nodes[1].copy()
     coin.reseed(trace_root)
-    # 2. constraint composition coefficients (linear batching: one draw per constraint, transition first), evaluation
-    cc_t = np.stack([coin.draw(D) for _ in range(nt)])
-    cc_b = np.stack([coin.draw(D) for _ in range(na)])
+    # 1b. the auxiliary segment (lib.rs:320-346): draw its random elements, build it, commit to it
+    if aux:
+        rand = np.stack([coin.draw(D) for _ in range(nr)])                   # Air::get_aux_rand_elements, air/src/air/mod.rs:292-306
+        aux_trace = aux["build"](D, rand.reshape(-1))
+        apolys, alde, aleaves, anodes = fld.build_trace_commitment(hasher_id, aux_trace, b, offset, D=D)
+        aux_root = anodes[1].copy()
+        coin.reseed(aux_root)
+        art.update(aux_rand_elements=rand, aux_trace=aux_trace, aux_root=aux_root, aux_polys=apolys, aux_lde=alde, aux_leaves=aleaves,
+                   aux_nodes=anodes, aux_width=aw)
+    # 2. constraint composition coefficients (linear batching: one draw per constraint, transition first — main then auxiliary —
+    # then the assertions, main then auxiliary), evaluation
+    cc_t = np.stack([coin.draw(D) for _ in range(nt + nta)])
+    cc_b = np.stack([coin.draw(D) for _ in range(na + nxa)])
     assertions = sorted(ex["assertions"], key=lambda a: (0, a[1], a[0]))     # Ord for Assertion: stride, first_step, column
-    comp = fld.evaluate_constraints(ex["air"], lde, lde.shape[1] // W, n, b, ce_blowup, offset, D, cc_t.reshape(-1),
-                                    [(c, s, fld.pack([v])) for c, s, v in assertions], cc_b.reshape(-1))
+    if aux:
+        aux_assertions = sorted(aux["assertions"], key=lambda a: (0, a[1], a[0]))
+        lift = lambda v: fld.pack([to_internal(fld, v)] + [0] * (D - 1))
+        comp = fld.evaluate_constraints_full(ex["air"], lde, lde.shape[1] // W, alde, alde.shape[1] // W, n, b, ce_blowup, offset, D, cc_t.reshape(-1),
+                                             [(c, s, fld.pack([v])) for c, s, v in assertions], cc_b[:na].reshape(-1),
+                                             [(c, s, lift(v)) for c, s, v in aux_assertions], cc_b[na:].reshape(-1), rand.reshape(-1))
+    else:
+        comp = fld.evaluate_constraints(ex["air"], lde, lde.shape[1] // W, n, b, ce_blowup, offset, D, cc_t.reshape(-1),
+                                        [(c, s, fld.pack([v])) for c, s, v in assertions], cc_b.reshape(-1))
     # 3. composition polynomial (interpolate over the ce coset, cut into columns of n coefficients) and its commitment
     coeffs = fld.interpolate_poly_with_offset(comp, offset, D)
     assert not coeffs[ncols * n * ew:].any(), "composition polynomial does not fit its columns"
@@ -210,14 +245,17 @@ def prove(name, fld, hasher_id, n, options):
     zg = fld.pack(fld.ext_mul(D, fld.unpack(z), [g] + [0] * (D - 1)))
     t_cur = fld.evaluate_columns_at(polys, width, z, D, 1)
     t_next = fld.evaluate_columns_at(polys, width, zg, D, 1)
+    if aux:                                                                  # TracePolyTable::get_ood_frame: main columns, then auxiliary
+        t_cur = np.concatenate([t_cur, fld.evaluate_columns_at(apolys, aw, z, D, D)])
+        t_next = np.concatenate([t_next, fld.evaluate_columns_at(apolys, aw, zg, D, D)])
     q_cur = fld.evaluate_columns_at(cpoly, ncols, z, D, D)
     q_next = fld.evaluate_columns_at(cpoly, ncols, zg, D, D)
     ood = np.concatenate([t_cur.reshape(-1), q_cur.reshape(-1), t_next.reshape(-1), q_next.reshape(-1)])   # merge_ood_evaluations
     coin.reseed(h.hash_elements(ood))
-    dc_t = np.stack([coin.draw(D) for _ in range(width)])
+    dc_t = np.stack([coin.draw(D) for _ in range(width + aw)])
     dc_c = np.stack([coin.draw(D) for _ in range(ncols)])
-    deep = fld.deep_compose(polys, width, None, 0, cpoly, ncols, n, D, z, dc_t.reshape(-1), dc_c.reshape(-1), t_cur.reshape(-1), t_next.reshape(-1),
-                            q_cur.reshape(-1), q_next.reshape(-1))
+    deep = fld.deep_compose(polys, width, apolys if aux else None, aw, cpoly, ncols, n, D, z, dc_t.reshape(-1), dc_c.reshape(-1), t_cur.reshape(-1),
+                            t_next.reshape(-1), q_cur.reshape(-1), q_next.reshape(-1))
     deep_evals = fld.evaluate_poly_with_offset(deep, offset, b, D)
     # 5. FRI commit phase
     N = options.fri_folding_factor
@@ -248,7 +286,7 @@ def prove(name, fld, hasher_id, n, options):
                fri_remainder_commitment=rem_commitment, pow_seed=pow_seed, pow_nonce=nonce, query_positions=positions,
                trace_lde=lde, constraint_lde=q_lde, num_composition_columns=ncols,
                trace_leaves=leaves, trace_nodes=nodes, constraint_leaves=q_leaves, constraint_nodes=q_nodes, fri_layers=fri_layers,
-               width=width, n=n, num_constraints=na + nt)
+               width=width, n=n, num_constraints=na + nt + nta + nxa)
     return art
 
 
@@ -348,14 +386,18 @@ def proof_to_bytes(art, fld, hasher_id, options):
     ew = D * W
     n, width, pos = art["n"], art["width"], art["query_positions"]
     modulus = fld.M.to_bytes(8 * W, "little")
-    out = bytes([width, 0, 0, n.bit_length() - 1]) + (0).to_bytes(2, "little")                  # TraceInfo: no aux segment, no metadata
+    aw = art.get("aux_width", 0)
+    out = bytes([width, aw, len(art["aux_rand_elements"]) if aw else 0, n.bit_length() - 1]) + (0).to_bytes(2, "little")   # TraceInfo (trace_info.rs:240-263), no metadata
     out += bytes([len(modulus)]) + modulus
     out += bytes([options.num_queries, options.blowup_factor, options.grinding_factor, D, N, options.fri_remainder_max_degree, 0, 0, 1, 1])
     out += vint(art["num_constraints"])
     out += bytes([len(pos)])
-    com = b"".join(h.digest_as_bytes(c) for c in [art["trace_root"], art["constraint_root"]] + art["fri_roots"] + [art["fri_remainder_commitment"]])
+    roots = [art["trace_root"]] + ([art["aux_root"]] if aw else []) + [art["constraint_root"]] + art["fri_roots"] + [art["fri_remainder_commitment"]]
+    com = b"".join(h.digest_as_bytes(c) for c in roots)
     out += len(com).to_bytes(2, "little") + com
     out += _queries_bytes(fld, h, art["trace_lde"][pos][:, :width * W], art["trace_leaves"], art["trace_nodes"], pos)
+    if aw:                                                                                                                    # one Queries per trace segment
+        out += _queries_bytes(fld, h, art["aux_lde"][pos][:, :aw * ew], art["aux_leaves"], art["aux_nodes"], pos)
     ncols = art["num_composition_columns"]
     out += _queries_bytes(fld, h, art["constraint_lde"][pos][:, :ncols * ew], art["constraint_leaves"], art["constraint_nodes"], pos)
     for cur, nxt in (art["ood_trace_frame"], art["ood_constraint_frame"]):

@@ -95,3 +95,54 @@ def test_usize_encoding(oracle):
     assert op.vint(2**56 - 1) == b"\x80" + b"\xff" * 7 and op.vint(2**56) == b"\x00" + (2**56).to_bytes(8, "little")
     for v in list(range(0, 70000, 37)) + [2**k + d for k in range(7, 64, 7) for d in (-1, 0, 1)] + [2**64 - 1]:
         assert write_usize(v) == op.vint(v), v
+
+
+@pytest.mark.parametrize("n,D", [(64, 2), (128, 1)])
+def test_cpu_prover_with_an_auxiliary_segment_satisfies_the_verifiers_checks(oracle, n, D):
+    """examples::rescue_raps through the whole CPU prover: the auxiliary random elements are drawn after the main commitment,
+    the aux segment is committed before the constraint coefficients are drawn, and the out-of-domain equation — with the aux
+    frame, the aux transition constraints and the aux assertions — holds at the drawn point with the drawn coefficients."""
+    from oracle import prover as op
+    fld = oracle.f128
+    opts = op.Options(12, 8, 3, D, 4, 7)
+    art = op.prove("rescue_raps", fld, 0, n, opts)
+    ex = op.example("rescue_raps", fld, n)
+    aux = ex["aux"]
+    E = Ext(fld, D, 1)
+    # transcript order: re-derive the aux random elements from the coin state after the main commitment
+    h = op.Hasher(0, fld)
+    coin = op.Coin(h, fld.pack(art["context_elements"] + art["pub_inputs"]))
+    assert np.array_equal(coin.seed, art["coin_seed"])
+    coin.reseed(art["trace_root"])
+    assert np.array_equal(np.stack([coin.draw(D) for _ in range(3)]), art["aux_rand_elements"])
+    coin.reseed(art["aux_root"])
+    cc_t, cc_b = art["constraint_coefficients"]
+    assert np.array_equal(np.stack([coin.draw(D) for _ in range(11)]), cc_t) and cc_b.shape[0] == 10
+    assert art["context_elements"][0] == (((8 << 8 | 1) << 8 | 3) << 8) | 3 and art["context_elements"][4] == 8 + 8 + 3 + 2
+    # the permutation column closes
+    assert fld.unpack(art["aux_trace"][2])[-D:] == [1] + [0] * (D - 1)
+    # the out-of-domain equation
+    z = fld.unpack(art["ood_point"])
+    t_cur, t_next = art["ood_trace_frame"]
+    q_cur, _ = art["ood_constraint_frame"]
+    assert t_cur.shape[0] == 11
+    zn = E.pow(z, n)
+    H, zi = [0] * D, E.lift(1)
+    for i in range(art["num_composition_columns"]):
+        H = E.add(H, E.mul(zi, fld.unpack(q_cur[i])))
+        zi = E.mul(zi, zn)
+    per = fld.evaluate_columns_at(fld.air_periodic_polys(7), 10, fld.pack(E.pow(z, n // 16)), D, 1).reshape(-1)
+    tev = fld.unpack(fld.air_evaluate_transition(7, D, t_cur[:8].reshape(-1), t_next[:8].reshape(-1), per))
+    aev = fld.unpack(fld.air_evaluate_aux_transition(7, D, D, t_cur[:8].reshape(-1), t_next[:8].reshape(-1), t_cur[8:].reshape(-1),
+                                                     t_next[8:].reshape(-1), per, art["aux_rand_elements"].reshape(-1)))
+    evals = [tev[k * D:(k + 1) * D] for k in range(8)] + [aev[k * D:(k + 1) * D] for k in range(3)]
+    ood_cur = [fld.unpack(r) for r in t_cur]
+    assertions = sorted(ex["assertions"], key=lambda a: (0, a[1], a[0]))
+    for col, step, val in sorted(aux["assertions"], key=lambda a: (0, a[1], a[0])):
+        ood_cur.append(E.sub(ood_cur[8 + col], E.lift(val)))
+        assertions.append((len(ood_cur) - 1, step, 0))
+    g = fld.root_of_unity(n.bit_length() - 1)
+    assert ood_constraint_equation_holds(E, 1, g, n, z, H, evals, [fld.unpack(c) for c in cc_t], ood_cur, assertions, [fld.unpack(c) for c in cc_b])
+    # and it serialises: TraceInfo announces the segment, both trace segments are opened
+    proof = op.proof_to_bytes(art, fld, 0, opts)
+    assert proof[:4] == bytes([8, 3, 3, n.bit_length() - 1])

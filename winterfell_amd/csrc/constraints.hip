@@ -1,6 +1,7 @@
 // Constraint evaluation over the constraint-evaluation domain for the reference's example AIRs.
 //
-// Reference behaviour reproduced (single-segment traces, single-value assertions):
+// Reference behaviour reproduced (single-value assertions; one optional auxiliary segment — evaluate_fragment_full,
+// evaluate_aux_transition, BoundaryConstraints::evaluate_all: default.rs:214-271,301-332, boundary.rs:103-115):
 //   DefaultConstraintEvaluator::evaluate / evaluate_fragment_main / evaluate_main_transition
 //                                         prover/src/constraints/evaluator/default.rs:52-106,165-210,277-299
 //   BoundaryConstraints::evaluate_main    prover/src/constraints/evaluator/boundary.rs:86-97,213-232,318-327
@@ -41,7 +42,7 @@ constexpr int INV_CHUNK = 16;
 
 // ---- AIRs -------------------------------------------------------------------------------------------------------
 struct AirFibSmall {
-    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1, AUX_WIDTH = 0, NTA = 0, NR = 0;
     struct Consts {};
     template <class F>
     static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
@@ -52,7 +53,7 @@ struct AirFibSmall {
 };
 
 struct AirFib8 {      // examples/src/fibonacci/fib8/air.rs:40-65
-    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1, AUX_WIDTH = 0, NTA = 0, NR = 0;
     struct Consts {};
     template <class F>
     static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
@@ -69,7 +70,7 @@ struct AirFib8 {      // examples/src/fibonacci/fib8/air.rs:40-65
 };
 
 struct AirMulFib2 {   // examples/src/fibonacci/mulfib2/air.rs:41-60
-    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    static constexpr int WIDTH = 2, NT = 2, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1, AUX_WIDTH = 0, NTA = 0, NR = 0;
     struct Consts {};
     template <class F>
     static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
@@ -80,7 +81,7 @@ struct AirMulFib2 {   // examples/src/fibonacci/mulfib2/air.rs:41-60
 };
 
 struct AirMulFib8 {   // examples/src/fibonacci/mulfib8/air.rs:52-82
-    static constexpr int WIDTH = 8, NT = 8, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1;
+    static constexpr int WIDTH = 8, NT = 8, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = 1, AUX_WIDTH = 0, NTA = 0, NR = 0;
     struct Consts {};
     template <class F>
     static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *,
@@ -95,7 +96,7 @@ struct AirMulFib8 {   // examples/src/fibonacci/mulfib8/air.rs:52-82
 // examples/src/vdf/regular/air.rs:49-61 (EX = 1) and vdf/exempt/air.rs (EX = 2: the last TWO steps are exempt)
 template <int EX>
 struct AirVdf {
-    static constexpr int WIDTH = 1, NT = 1, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = EX;   // degree 3: ce_blowup = npo2(3 - 1) = 2 (degree.rs:96-99)
+    static constexpr int WIDTH = 1, NT = 1, NP = 0, CYCLE = 0, LOG_CE = 1, EXEMPT = EX, AUX_WIDTH = 0, NTA = 0, NR = 0;   // degree 3: ce_blowup = npo2(3 - 1) = 2 (degree.rs:96-99)
     struct Consts {
         f128::u128 forty_two;    // BaseElement::new(42) in the field's internal form (low word for the 64-bit fields)
     };
@@ -109,7 +110,7 @@ struct AirVdf {
 };
 
 struct AirRescue {   // F128 only
-    static constexpr int WIDTH = 4, NT = 4, NP = 9, CYCLE = 16, LOG_CE = 2, EXEMPT = 1;
+    static constexpr int WIDTH = 4, NT = 4, NP = 9, CYCLE = 16, LOG_CE = 2, EXEMPT = 1, AUX_WIDTH = 0, NTA = 0, NR = 0;
     struct Consts {
         f128::u128 mds[16], inv_mds[16];
     };
@@ -125,12 +126,11 @@ struct AirRescue {   // F128 only
 #pragma unroll
         for (int i = 0; i < 4; i++) st[i] = r[i];
     }
+    // rescue::enforce_round (examples/src/rescue/rescue.rs:60-89) without the flag: d[i] = step2[i] - step1[i]
     template <class F>
-    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *per,
-                                                      const Consts &c, typename F::T *res) {
+    static __device__ __forceinline__ void round_diff(const typename F::T *cur, const typename F::T *next, const typename F::T *ark,
+                                                      const Consts &c, typename F::T (&d)[4]) {
         typedef typename F::T T;
-        const T flag = per[0];
-        const T *ark = per + 1;
         T s1[4], s2[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) s1[i] = F::mul(F::mul(cur[i], cur[i]), cur[i]);           // apply_sbox
@@ -142,13 +142,76 @@ struct AirRescue {   // F128 only
         mds<F>(s2, c.inv_mds);
 #pragma unroll
         for (int i = 0; i < 4; i++) s2[i] = F::mul(F::mul(s2[i], s2[i]), s2[i]);
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[i] = F::sub(s2[i], s1[i]);
+    }
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *per,
+                                                      const Consts &c, typename F::T *res) {
+        typedef typename F::T T;
+        const T flag = per[0];
+        T d[4];
+        round_diff<F>(cur, next, per + 1, c, d);
         const T copy_flag = F::sub((T)1, flag);                                               // not(hash_flag); f128: ONE = 1
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const T round = F::mul(flag, F::sub(s2[i], s1[i]));
+            const T round = F::mul(flag, d[i]);
             const T copy = F::mul(copy_flag, i < 2 ? F::sub(cur[i], next[i]) : next[i]);
             res[i] = F::add(round, copy);
         }
+    }
+};
+
+// RescueRapsAir (examples/src/rescue_raps/air.rs:60-253), F128 only: two Rescue chains side by side and an auxiliary segment of
+// three columns over E that carries the permutation argument between the values the chains absorb.
+struct AirRescueRaps {
+    static constexpr int WIDTH = 8, NT = 8, NP = 10, CYCLE = 16, LOG_CE = 2, EXEMPT = 1, AUX_WIDTH = 3, NTA = 3, NR = 3;
+    typedef AirRescue::Consts Consts;
+    template <class F>
+    static __device__ __forceinline__ void transition(const typename F::T *cur, const typename F::T *next, const typename F::T *per,
+                                                      const Consts &c, typename F::T *res) {   // air.rs:91-153
+        typedef typename F::T T;
+        const T hash_flag = per[0], absorption_flag = per[1];
+        const T copy_flag = F::sub((T)1, F::add(hash_flag, absorption_flag));
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            T d[4];
+            AirRescue::round_diff<F>(cur + 4 * h, next + 4 * h, per + 2, c, d);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const T same = F::sub(cur[4 * h + i], next[4 * h + i]);
+                T r = F::add(F::mul(hash_flag, d[i]), F::mul(copy_flag, same));               // enforce_round + enforce_hash_copy
+                if (i >= 2) r = F::add(r, F::mul(absorption_flag, same));                     // capacity registers stay put while absorbing
+                res[4 * h + i] = r;
+            }
+        }
+    }
+    // evaluate_aux_transition, air.rs:155-214: main frame over the base field, aux frame / rand / result over E (D words each)
+    template <class F, int D>
+    static __device__ __forceinline__ void aux_transition(const typename F::T *cur, const typename F::T *next, const typename F::T (*acur)[D],
+                                                          const typename F::T (*anext)[D], const typename F::T *per,
+                                                          const typename F::T (*rand)[D], typename F::T (*res)[D]) {
+        typedef typename F::T T;
+        const T absorption_flag = per[1];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const T d0 = F::sub(next[4 * h], cur[4 * h]), d1 = F::sub(next[4 * h + 1], cur[4 * h + 1]);
+#pragma unroll
+            for (int d = 0; d < D; d++) {                                                     // flag * (aux[h] - (r0 * d0 + r1 * d1)), base * E
+                const T copied = F::add(F::mul(rand[0][d], d0), F::mul(rand[1][d], d1));
+                res[h][d] = F::mul(absorption_flag, F::sub(acur[h][d], copied));
+            }
+        }
+        T a[D], b[D], u[D], v[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            a[d] = F::add(acur[1][d], rand[2][d]);
+            b[d] = F::add(acur[0][d], rand[2][d]);
+        }
+        F::template ext_mul<D>(anext[2], a, u);
+        F::template ext_mul<D>(acur[2], b, v);
+#pragma unroll
+        for (int d = 0; d < D; d++) res[2][d] = F::sub(u[d], v[d]);
     }
 };
 
@@ -200,6 +263,14 @@ struct EvalParams {
     const uint32_t *a_col, *a_group;
     const T *a_val;               // [num_assert]
     const T *cc_b;                // [num_assert][D]
+    // the auxiliary segment (AIR::AUX_WIDTH > 0): rows of AUX_WIDTH elements of E
+    const T *aux_lde;
+    uint64_t aux_row_width;       // in base elements
+    const T *rand;                // [NR][D]
+    uint32_t num_aux_assert;
+    const uint32_t *x_col, *x_group;
+    const T *x_val;               // [num_aux_assert][D]
+    const T *cc_x;                // [num_aux_assert][D]
     T *out;                       // [ce][D]
 };
 
@@ -233,6 +304,36 @@ __global__ __launch_bounds__(256) void constraints_kernel(EvalParams<typename F:
 #pragma unroll
         for (int k = 1; k < AIR::NT; k++) acc[d] = F::add(acc[d], F::mul(p.cc_t[k * D + d], tev[k]));
     }
+    // the auxiliary segment's transition constraints join the same sum, coefficient times evaluation over E
+    // (evaluate_fragment_full / evaluate_aux_transition, default.rs:214-271,301-332)
+    constexpr int AW = AIR::AUX_WIDTH > 0 ? AIR::AUX_WIDTH : 1;
+    T acur[AW][D];
+    if constexpr (AIR::AUX_WIDTH > 0) {
+        const T *ac = p.aux_lde + lde_step * p.aux_row_width;
+        const T *an = p.aux_lde + ((lde_step + (1ull << p.log_lde_blowup)) & (lde_rows - 1)) * p.aux_row_width;
+        T anext[AW][D], rnd[AIR::NR][D], aev[AIR::NTA][D];
+#pragma unroll
+        for (int k = 0; k < AIR::AUX_WIDTH; k++)
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                acur[k][d] = F::load_norm(ac[k * D + d]);
+                anext[k][d] = F::load_norm(an[k * D + d]);
+            }
+#pragma unroll
+        for (int k = 0; k < AIR::NR; k++)
+#pragma unroll
+            for (int d = 0; d < D; d++) rnd[k][d] = p.rand[k * D + d];
+        AIR::template aux_transition<F, D>(cur, next, acur, anext, per, rnd, aev);
+#pragma unroll
+        for (int k = 0; k < AIR::NTA; k++) {
+            T cc[D], t[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) cc[d] = p.cc_t[(AIR::NT + k) * D + d];
+            F::template ext_mul<D>(cc, aev[k], t);
+#pragma unroll
+            for (int d = 0; d < D; d++) acc[d] = F::add(acc[d], t[d]);
+        }
+    }
     const T x = series_at<F>(p.x_lo, p.x_hi, p.x_log_lo, step);
     T ze = F::mul(p.zt[step & ((1u << p.log_ce_blowup) - 1)], F::sub(x, p.exempt));
     if (AIR::EXEMPT == 2) ze = F::mul(ze, F::sub(x, p.exempt2));
@@ -252,6 +353,24 @@ __global__ __launch_bounds__(256) void constraints_kernel(EvalParams<typename F:
             const T ev = F::sub(sv, p.a_val[k]);
 #pragma unroll
             for (int d = 0; d < D; d++) grp[d] = F::add(grp[d], F::mul(p.cc_b[k * D + d], ev));
+        }
+        if constexpr (AIR::AUX_WIDTH > 0) {                       // aux single-value assertions of this divisor (boundary.rs:241-266)
+            for (uint32_t k = 0; k < p.num_aux_assert; k++) {
+                if (p.x_group[k] != q) continue;
+                const uint32_t col = p.x_col[k];
+                T ev[D], cc[D], t[D];
+#pragma unroll
+                for (int d = 0; d < D; d++) {
+                    T sv = acur[0][d];
+#pragma unroll
+                    for (int c = 1; c < AIR::AUX_WIDTH; c++) sv = col == (uint32_t)c ? acur[c][d] : sv;
+                    ev[d] = F::sub(sv, p.x_val[k * D + d]);
+                    cc[d] = p.cc_x[k * D + d];
+                }
+                F::template ext_mul<D>(cc, ev, t);
+#pragma unroll
+                for (int d = 0; d < D; d++) grp[d] = F::add(grp[d], t[d]);
+            }
         }
         const T z = p.zb[(uint64_t)q * ce + step];
 #pragma unroll
@@ -293,9 +412,17 @@ template <> void periodic_values<HostF128, AirRescue>(std::vector<std::vector<Ho
         for (int i = 0; i < 16; i++) cols[1 + j][i] = RESCUE_ARK[i][j];      // get_round_constants, rescue.rs:92-107
 }
 
+template <> void periodic_values<HostF128, AirRescueRaps>(std::vector<std::vector<HostF128::T>> &cols) {
+    cols.assign(10, std::vector<HostF128::T>(16));
+    for (int i = 0; i < 16; i++) cols[0][i] = i < 14 ? 1 : 0;                 // CYCLE_MASK, examples/src/rescue_raps/air.rs:22-39
+    for (int i = 0; i < 16; i++) cols[1][i] = i == 14 ? 1 : 0;                // the absorption column, air.rs:243-245
+    for (int j = 0; j < 8; j++)
+        for (int i = 0; i < 16; i++) cols[2 + j][i] = RESCUE_ARK[i][j];
+}
+
 template <class HF, class AIR>
 static void fill_consts(typename AIR::Consts &c) {
-    if constexpr (std::is_same<AIR, AirRescue>::value) {
+    if constexpr (std::is_same<AIR, AirRescue>::value || std::is_same<AIR, AirRescueRaps>::value) {
         for (int i = 0; i < 16; i++) {
             c.mds[i] = RESCUE_MDS[i];
             c.inv_mds[i] = RESCUE_INV_MDS[i];
@@ -307,12 +434,26 @@ static void fill_consts(typename AIR::Consts &c) {
     }
 }
 
+// the auxiliary segment's side of a call (all NULL / 0 for a single-segment AIR)
+struct AuxArgs {
+    const void *d_lde = nullptr;
+    uint64_t row_width = 0;                 // base elements per row
+    uint32_t num_assert = 0;
+    const uint32_t *h_cols = nullptr;
+    const uint64_t *h_steps = nullptr;
+    const void *h_vals = nullptr, *h_cc = nullptr, *h_rand = nullptr;
+};
+
 template <class HF, class AIR, int D>
 static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup,
                     const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols, const uint64_t *h_steps,
-                    const void *h_vals, const void *h_cc_b, void *d_out) {
+                    const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs()) {
     typedef typename HF::T T;
     typedef typename HF::Dev F;
+    if ((AIR::AUX_WIDTH > 0) != (aux.d_lde != nullptr)) return WF_ERR_INVALID_ARG;     // a multi-segment AIR comes with its aux segment, the others without
+    if (AIR::AUX_WIDTH > 0 && (aux.row_width < (uint64_t)AIR::AUX_WIDTH * D || !aux.h_rand || aux.num_assert > MAX_ASSERT ||
+                               (aux.num_assert && (!aux.h_cols || !aux.h_steps || !aux.h_vals || !aux.h_cc))))
+        return WF_ERR_INVALID_ARG;
     if (log_ce_blowup != (uint32_t)AIR::LOG_CE) return WF_ERR_INVALID_ARG;          // AirContext fixes ce_blowup (context.rs:104-117)
     if (log_lde_blowup < log_ce_blowup) return WF_ERR_INVALID_ARG;                  // "blowup factor too small" (context.rs:119-124)
     if (row_width < (uint64_t)AIR::WIDTH || num_assert == 0 || num_assert > MAX_ASSERT) return WF_ERR_INVALID_ARG;
@@ -329,7 +470,9 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     uint64_t gsteps[MAX_GROUPS];
     uint32_t ngroups = 0;
     std::vector<uint32_t> a_group(num_assert), a_col(num_assert);
-    std::vector<T> a_val(num_assert), cc_b((size_t)num_assert * D), cc_t((size_t)AIR::NT * D);
+    std::vector<T> a_val(num_assert), cc_b((size_t)num_assert * D), cc_t((size_t)(AIR::NT + AIR::NTA) * D);
+    std::vector<uint32_t> x_group(aux.num_assert + 1), x_col(aux.num_assert + 1);
+    std::vector<T> x_val((size_t)aux.num_assert * D + 1), cc_x((size_t)aux.num_assert * D + 1), rnd((size_t)AIR::NR * D + 1);
     for (uint32_t k = 0; k < num_assert; k++) {
         if (h_cols[k] >= (uint32_t)AIR::WIDTH || h_steps[k] >= n) return WF_ERR_INVALID_ARG;
         uint32_t q = 0;
@@ -343,6 +486,25 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
         memcpy((void *)&a_val[k], (const uint8_t *)h_vals + (size_t)k * sizeof(T), sizeof(T));
         if (!HF::valid_internal(a_val[k])) return WF_ERR_INVALID_ARG;
         a_val[k] = HF::to_internal(HF::from_internal(a_val[k]));               // normalise lazy f62 words
+    }
+    for (uint32_t k = 0; k < aux.num_assert; k++) {                            // aux assertions join the group of their step (boundary.rs:58-73)
+        if (aux.h_cols[k] >= (uint32_t)AIR::AUX_WIDTH || aux.h_steps[k] >= n) return WF_ERR_INVALID_ARG;
+        uint32_t q = 0;
+        while (q < ngroups && gsteps[q] != aux.h_steps[k]) q++;
+        if (q == ngroups) {
+            if (ngroups == MAX_GROUPS) return WF_ERR_UNSUPPORTED;
+            gsteps[ngroups++] = aux.h_steps[k];
+        }
+        x_group[k] = q;
+        x_col[k] = aux.h_cols[k];
+    }
+    if (AIR::AUX_WIDTH > 0) {
+        memcpy((void *)x_val.data(), aux.h_vals, (size_t)aux.num_assert * D * sizeof(T));
+        memcpy((void *)cc_x.data(), aux.h_cc, (size_t)aux.num_assert * D * sizeof(T));
+        memcpy((void *)rnd.data(), aux.h_rand, (size_t)AIR::NR * D * sizeof(T));
+        x_val.back() = cc_x.back() = rnd.back() = 0;
+        for (auto *vec : {&x_val, &cc_x, &rnd})
+            for (auto &v : *vec) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
     }
     memcpy((void *)cc_b.data(), h_cc_b, cc_b.size() * sizeof(T));
     memcpy((void *)cc_t.data(), h_cc_t, cc_t.size() * sizeof(T));
@@ -401,13 +563,15 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     }
 
     // device staging: one scratch block
-    const size_t w_zb = (size_t)ngroups * ce, w_small = ptab.size() + zt.size() + bvals.size() + a_val.size() + cc_b.size() + cc_t.size();
-    const size_t bytes = (w_zb + w_small) * sizeof(T) + 2 * (size_t)num_assert * sizeof(uint32_t) + 64;
+    const size_t w_zb = (size_t)ngroups * ce, w_small = ptab.size() + zt.size() + bvals.size() + a_val.size() + cc_b.size() + cc_t.size() +
+                                                        x_val.size() + cc_x.size() + rnd.size();
+    const size_t bytes = (w_zb + w_small) * sizeof(T) + 2 * ((size_t)num_assert + x_col.size()) * sizeof(uint32_t) + 64;
     void *tmp;
     WF_TRY(wf_scratch(ctx, 0, bytes, &tmp));
     T *d_zb = (T *)tmp, *d_ptab = d_zb + w_zb, *d_zt = d_ptab + ptab.size(), *d_b = d_zt + zt.size(), *d_aval = d_b + bvals.size(),
-      *d_ccb = d_aval + a_val.size(), *d_cct = d_ccb + cc_b.size();
-    uint32_t *d_acol = (uint32_t *)(d_cct + cc_t.size()), *d_agrp = d_acol + num_assert;
+      *d_ccb = d_aval + a_val.size(), *d_cct = d_ccb + cc_b.size(), *d_xval = d_cct + cc_t.size(), *d_ccx = d_xval + x_val.size(),
+      *d_rnd = d_ccx + cc_x.size();
+    uint32_t *d_acol = (uint32_t *)(d_rnd + rnd.size()), *d_agrp = d_acol + num_assert, *d_xcol = d_agrp + num_assert, *d_xgrp = d_xcol + x_col.size();
     auto up = [&](void *dst, const void *src, size_t nbytes) { return hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream); };
     WF_HIP(up(d_ptab, ptab.data(), ptab.size() * sizeof(T)));
     WF_HIP(up(d_zt, zt.data(), zt.size() * sizeof(T)));
@@ -417,6 +581,13 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     WF_HIP(up(d_cct, cc_t.data(), cc_t.size() * sizeof(T)));
     WF_HIP(up(d_acol, a_col.data(), num_assert * sizeof(uint32_t)));
     WF_HIP(up(d_agrp, a_group.data(), num_assert * sizeof(uint32_t)));
+    if (AIR::AUX_WIDTH > 0) {
+        WF_HIP(up(d_xval, x_val.data(), x_val.size() * sizeof(T)));
+        WF_HIP(up(d_ccx, cc_x.data(), cc_x.size() * sizeof(T)));
+        WF_HIP(up(d_rnd, rnd.data(), rnd.size() * sizeof(T)));
+        WF_HIP(up(d_xcol, x_col.data(), x_col.size() * sizeof(uint32_t)));
+        WF_HIP(up(d_xgrp, x_group.data(), x_group.size() * sizeof(uint32_t)));
+    }
     WF_HIP(hipStreamSynchronize(ctx->stream));      // host vectors die with this frame
 
     SeriesTable xs;
@@ -453,6 +624,14 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.a_group = d_agrp;
     p.a_val = d_aval;
     p.cc_b = d_ccb;
+    p.aux_lde = (const T *)aux.d_lde;
+    p.aux_row_width = aux.row_width;
+    p.rand = d_rnd;
+    p.num_aux_assert = aux.num_assert;
+    p.x_col = d_xcol;
+    p.x_group = d_xgrp;
+    p.x_val = d_xval;
+    p.cc_x = d_ccx;
     p.out = (T *)d_out;
     typename AIR::Consts consts;
     fill_consts<HF, AIR>(consts);
@@ -466,11 +645,11 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
 template <class HF, class AIR>
 static int evaluate_d(wf_ctx *ctx, uint32_t D, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup,
                       uint32_t log_ce_blowup, const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols,
-                      const uint64_t *h_steps, const void *h_vals, const void *h_cc_b, void *d_out) {
-    if (D == 1) return evaluate<HF, AIR, 1>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
-    if (D == 2) return evaluate<HF, AIR, 2>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
+                      const uint64_t *h_steps, const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs()) {
+    if (D == 1) return evaluate<HF, AIR, 1>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
+    if (D == 2) return evaluate<HF, AIR, 2>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
     if constexpr (HF::Dev::MAX_EXT >= 3)
-        if (D == 3) return evaluate<HF, AIR, 3>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out);
+        if (D == 3) return evaluate<HF, AIR, 3>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
     return WF_ERR_UNSUPPORTED;
 }
 
@@ -514,4 +693,33 @@ extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t
     }
 #undef WF_EVAL
     return WF_ERR_UNSUPPORTED;
+}
+
+extern "C" int wf_evaluate_constraints_aux(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_main_lde, uint64_t main_row_width,
+                                           const void *d_aux_lde, uint64_t aux_row_width, uint32_t log_n, uint32_t log_lde_blowup,
+                                           uint32_t log_ce_blowup, const void *h_domain_offset, const void *h_cc_transition,
+                                           uint32_t num_assertions, const uint32_t *h_assert_columns, const uint64_t *h_assert_steps,
+                                           const void *h_assert_values, const void *h_cc_boundary, uint32_t num_aux_assertions,
+                                           const uint32_t *h_aux_assert_columns, const uint64_t *h_aux_assert_steps,
+                                           const void *h_aux_assert_values, const void *h_cc_aux_boundary, const void *h_aux_rand_elements,
+                                           void *d_out) {
+    if (!ctx || !d_main_lde || !d_aux_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps ||
+        !h_assert_values || !h_cc_boundary || !h_aux_rand_elements || !d_out)
+        return WF_ERR_INVALID_ARG;
+    AuxArgs aux;
+    aux.d_lde = d_aux_lde;
+    aux.row_width = aux_row_width;
+    aux.num_assert = num_aux_assertions;
+    aux.h_cols = h_aux_assert_columns;
+    aux.h_steps = h_aux_assert_steps;
+    aux.h_vals = h_aux_assert_values;
+    aux.h_cc = h_cc_aux_boundary;
+    aux.h_rand = h_aux_rand_elements;
+    if (air == WF_AIR_RESCUE_RAPS) {
+        if (field != WF_FIELD_F128) return WF_ERR_UNSUPPORTED;   // examples/src/rescue_raps/mod.rs:13: f128
+        return evaluate_d<HostF128, AirRescueRaps>(ctx, ext_degree, d_main_lde, main_row_width, log_n, log_lde_blowup, log_ce_blowup,
+                                                   h_domain_offset, h_cc_transition, num_assertions, h_assert_columns, h_assert_steps,
+                                                   h_assert_values, h_cc_boundary, d_out, aux);
+    }
+    return WF_ERR_UNSUPPORTED;                                   // the other built-in AIRs have no auxiliary segment
 }
