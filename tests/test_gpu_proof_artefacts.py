@@ -31,12 +31,19 @@ def _run(oracle, example, fname, hname, n, D, num_queries=28, blowup=8, grinding
     # ---- GPU: the product's prove() on the same trace, public inputs the way the example's PublicInputs::to_elements lists them
     ex = oprover.example(example, ofld, n)
     trace = ex["trace"]
+    build_aux = None
     if example == "fib_small":
         air = wair.FibSmall(n, ex["pub"][0], blowup, fld)
+    elif example == "rescue_raps":
+        air = wair.RescueRapsAir(n, [ex["pub"][:2], ex["pub"][2:]], blowup)
+        assert air.pub_inputs_elements() == ex["pub"]
+        # Prover::build_aux_trace is the user's code (examples/src/rescue_raps/prover.rs:157-205): here the oracle's restatement of
+        # it, fed with the random elements the product's channel drew
+        build_aux = lambda rand: prover.ColMatrix(ex["aux"]["build"](D, np.asarray(rand).reshape(-1)), D, ctx, fld)
     else:
         air = wair.RescueAir(n, ex["pub"][:2], ex["pub"][2:], blowup)
     options = prover.ProofOptions(num_queries, blowup, grinding, ext_degree=D, fri_folding_factor=folding, fri_remainder_max_degree=rem_deg)
-    proof = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, ex["pub"])
+    proof = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, ex["pub"], build_aux_trace=build_aux)
     return want, proof, fld, ctx
 
 
@@ -54,8 +61,12 @@ def _check(want, proof, fld):
         assert eq(np.asarray(got).reshape(-1), exp.reshape(-1)), what
     for got, exp in zip(proof.deep_coefficients, want["deep_coefficients"]):
         assert eq(np.asarray(got).reshape(-1), exp.reshape(-1)), "DEEP composition coefficients"
-    # commitments = [trace root, constraint root, FRI layer roots ..., remainder commitment] (channel.rs:87-98, fri channel)
-    roots = proof.commitments[2:]
+    # commitments = [trace root (one per segment), constraint root, FRI layer roots ..., remainder commitment] (channel.rs:87-98, fri channel)
+    aux = "aux_root" in want
+    if aux:
+        assert eq(np.asarray(proof.aux_rand_elements).reshape(-1), want["aux_rand_elements"].reshape(-1)), "auxiliary random elements"
+        assert eq(proof.aux_trace_commitment, want["aux_root"]) and eq(proof.commitments[1], want["aux_root"]), "auxiliary segment root"
+    roots = proof.commitments[3 if aux else 2:]
     assert len(roots) == len(want["fri_roots"]) + 1
     for k, (got, exp) in enumerate(zip(roots, want["fri_roots"] + [want["fri_remainder_commitment"]])):
         assert eq(got, exp), "FRI commitment %d" % k
@@ -65,9 +76,13 @@ def _check(want, proof, fld):
     assert eq(proof.pow_seed, want["pow_seed"]) and proof.pow_nonce == want["pow_nonce"], "proof-of-work nonce"
     assert list(proof.query_positions) == want["query_positions"], "query positions"
     # the opened rows are the oracle's LDE rows at those positions
-    (t_rows, _), = proof.trace_queries
+    t_rows = proof.trace_queries[0][0]
     c_rows, _ = proof.constraint_queries
     pos = want["query_positions"]
+    assert len(proof.trace_queries) == (2 if aux else 1)
+    if aux:
+        a_rows = np.asarray(proof.trace_queries[1][0])
+        assert eq(a_rows, want["aux_lde"][pos][:, : a_rows.shape[1]]), "queried auxiliary rows"
     assert eq(np.asarray(t_rows), want["trace_lde"][pos][:, : np.asarray(t_rows).shape[1]]), "queried trace rows"
     assert eq(np.asarray(c_rows), want["constraint_lde"][pos][:, : np.asarray(c_rows).shape[1]]), "queried constraint rows"
     # ... and the serialised proof (Proof::to_bytes, air/src/proof/mod.rs:189-199): context, commitments, queries with their batch
@@ -80,7 +95,8 @@ def _check(want, proof, fld):
 
 @pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 1), ("fib_small", "f64", "Rp64_256", 1 << 8, 2),
                                                       ("fib_small", "f64", "Blake3_256", 1 << 12, 3), ("rescue", "f128", "Blake3_256", 1 << 10, 2),
-                                                      ("rescue", "f128", "Blake3_256", 1 << 10, 1)])
+                                                      ("rescue", "f128", "Blake3_256", 1 << 10, 1),
+                                                      ("rescue_raps", "f128", "Blake3_256", 1 << 9, 2), ("rescue_raps", "f128", "Blake3_256", 1 << 10, 1)])
 def test_proof_artefacts_equal_the_cpu_prover(oracle, example, fname, hname, n, D):
     want, proof, fld, ctx = _run(oracle, example, fname, hname, n, D)
     _check(want, proof, fld)
@@ -98,6 +114,14 @@ def test_context_elements_follow_the_reference_encoding(oracle):
     assert context_to_elements(air, opts) == [4 << 8, 1 << 10, m & (2**64 - 1), m >> 64, 8, (2 << 24) | (4 << 16) | (31 << 8) | 8, 16, 28]
     from oracle import prover as oprover
     assert oprover.context_to_elements(m, 16, 4, 1 << 10, 8, oprover.Options(28, 8, 16, 2, 4, 31)) == context_to_elements(air, opts)
+
+
+def test_rescue_raps_example_with_its_auxiliary_segment_at_2_16_rows(oracle):
+    """examples::rescue_raps (two chains of 2^12 hashes, 8 + 3 columns) with the examples' default options: the multi-segment
+    flow — auxiliary random elements after the main commitment, the second trace commitment, constraint evaluation over both
+    frames, the wider OOD frame and DEEP composition, two trace openings — byte for byte the CPU prover's proof."""
+    want, proof, fld, ctx = _run(oracle, "rescue_raps", "f128", "Blake3_256", 1 << 16, 2)
+    _check(want, proof, fld)
 
 
 def test_rescue_example_at_full_size(oracle):

@@ -1,6 +1,7 @@
 """The slice of the reference's `air` crate the GPU constraint evaluator needs: Assertion::single, the AirContext
 arithmetic (ce_blowup_factor, number of composition columns, transition exemptions) and the example AIRs whose
-transition functions are built into the library (include/winterfell_hip.h: WF_AIR_FIB_SMALL, WF_AIR_RESCUE).
+transition functions are built into the library (include/winterfell_hip.h: WF_AIR_FIB_SMALL ... WF_AIR_RESCUE_RAPS), the last one
+with an auxiliary trace segment.
 
 Values are python ints in the field's INTERNAL representation (fields.Field.new / as_int)."""
 from .math import fields
@@ -45,10 +46,22 @@ class _BuiltinAir:
     AIR_ID = None
     TRACE_WIDTH = None
     FIELD = None
+    AUX_TRACE_WIDTH = 0            # TraceInfo::aux_segment_width: columns (over E) of the auxiliary segment, 0 = single segment
+    NUM_AUX_RANDS = 0              # TraceInfo::get_num_aux_segment_rand_elements
 
-    def __init__(self, trace_length, degrees, num_assertions, blowup_factor):
+    def __init__(self, trace_length, degrees, num_assertions, blowup_factor, aux_degrees=(), num_aux_assertions=0):
+        """AirContext::new / new_multi_segment (air/src/air/context.rs:65-189): main (and auxiliary) transition constraint degrees,
+        the number of assertions against each segment."""
         assert trace_length >= 8 and trace_length & (trace_length - 1) == 0       # TraceInfo::MIN_TRACE_LENGTH
-        self._n, self.degrees, self._num_assertions, self.blowup_factor = trace_length, degrees, num_assertions, blowup_factor
+        self._n, self.main_degrees, self.aux_degrees, self.blowup_factor = trace_length, list(degrees), list(aux_degrees), blowup_factor
+        self.degrees = self.main_degrees + self.aux_degrees
+        self._num_main_assertions, self._num_aux_assertions = num_assertions, num_aux_assertions
+        self._num_assertions = num_assertions + num_aux_assertions
+        if self.AUX_TRACE_WIDTH:
+            assert self.aux_degrees and num_aux_assertions, "a multi-segment AIR needs auxiliary constraints and assertions"   # context.rs:131-150
+        else:
+            assert not self.aux_degrees and not num_aux_assertions
+        degrees = self.degrees
         self._ce_blowup = max(d.min_blowup_factor() for d in degrees)               # context.rs:104-117
         assert blowup_factor >= self._ce_blowup, \
             "blowup factor too small; expected at least %d, but was %d" % (self._ce_blowup, blowup_factor)   # context.rs:119-124
@@ -65,8 +78,27 @@ class _BuiltinAir:
     def lde_domain_size(self):
         return self._n * self.blowup_factor
 
+    def is_multi_segment(self):
+        return self.AUX_TRACE_WIDTH > 0
+
+    def trace_width(self):
+        """TraceInfo::width: main + auxiliary columns"""
+        return self.TRACE_WIDTH + self.AUX_TRACE_WIDTH
+
     def num_transition_constraints(self):
         return len(self.degrees)
+
+    def num_main_transition_constraints(self):
+        return len(self.main_degrees)
+
+    def num_aux_transition_constraints(self):
+        return len(self.aux_degrees)
+
+    def num_main_assertions(self):
+        return self._num_main_assertions
+
+    def num_aux_assertions(self):
+        return self._num_aux_assertions
 
     def num_assertions(self):
         return self._num_assertions
@@ -83,9 +115,23 @@ class _BuiltinAir:
     def sorted_assertions(self):
         """prepare_assertions (air/src/air/boundary/mod.rs:181-208): the order composition coefficients are dealt in."""
         a = sorted(self.get_assertions(), key=Assertion.sort_key)
-        assert len(a) == self._num_assertions
+        assert len(a) == self._num_main_assertions, \
+            "expected %d assertions against main trace segment, but received %d" % (self._num_main_assertions, len(a))   # boundary/mod.rs:68-74
         for x in a:
             assert x.column < self.TRACE_WIDTH and x.first_step < self._n
+        return a
+
+    def get_aux_assertions(self, aux_rand_elements, ext_degree):
+        """Air::get_aux_assertions (air/src/air/mod.rs:271-279): assertions against the auxiliary segment, values in E (tuples
+        of ext_degree internal-form ints); none by default."""
+        return []
+
+    def sorted_aux_assertions(self, aux_rand_elements, ext_degree):
+        a = sorted(self.get_aux_assertions(aux_rand_elements, ext_degree), key=Assertion.sort_key)
+        assert len(a) == self._num_aux_assertions, \
+            "expected %d assertions against the auxiliary trace segment, but received %d" % (self._num_aux_assertions, len(a))  # boundary/mod.rs:76-82
+        for x in a:
+            assert x.column < self.AUX_TRACE_WIDTH and x.first_step < self._n and len(x.value) == ext_degree
         return a
 
 
@@ -118,6 +164,35 @@ class RescueAir(_BuiltinAir):
         last = self._n - 1
         return [Assertion.single(0, 0, self.seed[0]), Assertion.single(1, 0, self.seed[1]),
                 Assertion.single(0, last, self.result[0]), Assertion.single(1, last, self.result[1])]
+
+
+class RescueRapsAir(_BuiltinAir):
+    """examples/src/rescue_raps/air.rs:60-253 (f128): two Rescue hash chains side by side whose absorbed seeds are permutations
+    of each other; the randomised permutation argument lives in an auxiliary segment of three columns over E built from three
+    random elements."""
+    AIR_ID, TRACE_WIDTH, CYCLE_LENGTH = 7, 8, 16
+    AUX_TRACE_WIDTH, NUM_AUX_RANDS = 3, 3                                          # custom_trace_table.rs:93
+    FIELD = fields.f128
+
+    def __init__(self, trace_length, result, blowup_factor=8):
+        """result: [[a, b], [c, d]] the final rate registers of the two chains (PublicInputs, air.rs:45-53)"""
+        main = [TransitionConstraintDegree(3, [self.CYCLE_LENGTH]) for _ in range(8)]
+        aux = [TransitionConstraintDegree(1, [self.CYCLE_LENGTH]), TransitionConstraintDegree(1, [self.CYCLE_LENGTH]), TransitionConstraintDegree(2)]
+        super().__init__(trace_length, main, 8, blowup_factor, aux_degrees=aux, num_aux_assertions=2)   # new_multi_segment(.., 8, 2, ..), air.rs:78-87
+        self.result = [list(result[0]), list(result[1])]
+
+    def pub_inputs_elements(self):
+        return [self.result[0][0], self.result[0][1], self.result[1][0], self.result[1][1]]              # flatten_slice_elements
+
+    def get_assertions(self):
+        last = self._n - 1
+        return [Assertion.single(2, 0, 0), Assertion.single(3, 0, 0), Assertion.single(6, 0, 0), Assertion.single(7, 0, 0),
+                Assertion.single(0, last, self.result[0][0]), Assertion.single(1, last, self.result[0][1]),
+                Assertion.single(4, last, self.result[1][0]), Assertion.single(5, last, self.result[1][1])]
+
+    def get_aux_assertions(self, aux_rand_elements, ext_degree):
+        one = (self.FIELD.new(1),) + (0,) * (ext_degree - 1)                        # E::ONE, air.rs:236-239
+        return [Assertion.single(2, 0, one), Assertion.single(2, self._n - 1, one)]
 
 
 class Fib8(_BuiltinAir):

@@ -40,11 +40,13 @@ def proof_options_to_elements(options):
     return [buf, options.grinding_factor, options.num_queries]
 
 
-def context_to_elements(air, options, aux_width=0, num_aux_rands=0, meta=b""):
+def context_to_elements(air, options, aux_width=None, num_aux_rands=None, meta=b""):
     """Context::to_elements (air/src/proof/context.rs:106-137) for a built-in AIR, as canonical integers: trace info, the
     field modulus' little-endian bytes split into two elements, the number of constraints, the proof options."""
     f = air.FIELD
     nbytes = 8 * f.W
+    aux_width = air.AUX_TRACE_WIDTH if aux_width is None else aux_width
+    num_aux_rands = air.NUM_AUX_RANDS if num_aux_rands is None else num_aux_rands
     out = trace_info_to_elements(air.TRACE_WIDTH, air.trace_length(), nbytes, aux_width, num_aux_rands, meta)
     mb = f.M.to_bytes(nbytes, "little")
     out += [int.from_bytes(mb[:nbytes // 2], "little"), int.from_bytes(mb[nbytes // 2:], "little")]
@@ -82,6 +84,11 @@ class ProverChannel:
         self.public_coin.reseed(self.hasher.hash_elements(evals, self.ctx, field=self.air.FIELD))
 
     # ---- public coin (channel.rs:112-165); linear batching: one draw per coefficient (air/src/air/coefficients.rs:201-206)
+    def get_aux_rand_elements(self):
+        """Air::get_aux_rand_elements(channel.public_coin()) (air/src/air/mod.rs:292-306; prover/src/lib.rs:323-325): the random
+        elements the auxiliary trace segment is built from, drawn once the main segment is committed"""
+        return self.public_coin.draw_many(self.air.NUM_AUX_RANDS, self.options.ext_degree)
+
     def get_constraint_composition_coeffs(self):
         D = self.options.ext_degree
         self.public_coin.prefetch(self.air.num_transition_constraints() + self.air.num_assertions())
@@ -94,8 +101,8 @@ class ProverChannel:
 
     def get_deep_composition_coeffs(self):
         D = self.options.ext_degree
-        self.public_coin.prefetch(self.air.TRACE_WIDTH + self.air.num_constraint_composition_columns())
-        trace = self.public_coin.draw_many(self.air.TRACE_WIDTH, D)
+        self.public_coin.prefetch(self.air.trace_width() + self.air.num_constraint_composition_columns())
+        trace = self.public_coin.draw_many(self.air.trace_width(), D)            # TraceInfo::width: main + auxiliary columns
         constraints = self.public_coin.draw_many(self.air.num_constraint_composition_columns(), D)
         return trace, constraints
 

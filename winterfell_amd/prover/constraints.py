@@ -17,9 +17,14 @@ class ConstraintCompositionCoefficients:
 
 
 class DefaultConstraintEvaluator:
-    def __init__(self, air, composition_coefficients: ConstraintCompositionCoefficients, ext_degree=1):
+    def __init__(self, air, composition_coefficients: ConstraintCompositionCoefficients, ext_degree=1, aux_rand_elements=None):
+        """DefaultConstraintEvaluator::new(air, aux_rand_elements, composition_coefficients) (default.rs:128-160);
+        aux_rand_elements: (NUM_AUX_RANDS, ext_degree*W) words for a multi-segment AIR."""
         f = air.FIELD
         self.air, self.ext_degree, self.cc = air, ext_degree, composition_coefficients
+        assert (aux_rand_elements is not None) == air.is_multi_segment(), "expected aux rand elements to be present"   # default.rs:322-324
+        self.aux_rand_elements = None if aux_rand_elements is None else np.ascontiguousarray(aux_rand_elements, dtype=np.uint64)
+        self.aux_assertions = air.sorted_aux_assertions(self.aux_rand_elements, ext_degree) if air.is_multi_segment() else []
         ew = ext_degree * f.W
         assert self.cc.transition.size == air.num_transition_constraints() * ew, \
             "number of transition constraints must match the number of composition coefficient tuples"   # transition/mod.rs:37-41
@@ -43,6 +48,22 @@ class DefaultConstraintEvaluator:
         off = f.element_words(int(domain.offset))
         cct, ccb = self.cc.transition.reshape(-1), self.cc.boundary.reshape(-1)
         vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+        if air.is_multi_segment():
+            # evaluate_fragment_full (default.rs:214-271): frames from both segments; boundary coefficients: main assertions first
+            aux = trace_lde.aux_segment_lde
+            assert aux is not None, "expected aux segment to be present"
+            ew = D * f.W
+            nm = len(self.assertions)
+            xcols = np.array([a.column for a in self.aux_assertions], dtype=np.uint32)
+            xsteps = np.array([a.first_step for a in self.aux_assertions], dtype=np.uint64)
+            xvals = f.pack([v for a in self.aux_assertions for v in a.value])
+            ccm, ccx = np.ascontiguousarray(ccb[:nm * ew]), np.ascontiguousarray(ccb[nm * ew:])
+            rnd = self.aux_rand_elements.reshape(-1)
+            assert rnd.size == air.NUM_AUX_RANDS * ew
+            ctx.call("wf_evaluate_constraints_aux", air.AIR_ID, f.ID, D, ptr(lde.data), lde.row_width, ptr(aux.data), aux.row_width,
+                     n.bit_length() - 1, domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), nm, vp(cols),
+                     vp(steps), vp(vals), vp(ccm), len(self.aux_assertions), vp(xcols), vp(xsteps), vp(xvals), vp(ccx), vp(rnd), ptr(out))
+            return out
         ctx.call("wf_evaluate_constraints", air.AIR_ID, f.ID, D, ptr(lde.data), lde.row_width, n.bit_length() - 1,
                  domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), len(self.assertions),
                  vp(cols), vp(steps), vp(vals), vp(ccb), ptr(out))

@@ -69,7 +69,8 @@ def proof_options_to_bytes(options, num_partitions=1, hash_rate=1):
 def context_to_bytes(air, options):
     f = air.FIELD
     modulus = f.M.to_bytes(8 * f.W, "little")
-    return (trace_info_to_bytes(air.TRACE_WIDTH, air.trace_length()) + bytes([len(modulus)]) + modulus + proof_options_to_bytes(options) +
+    return (trace_info_to_bytes(air.TRACE_WIDTH, air.trace_length(), air.AUX_TRACE_WIDTH, air.NUM_AUX_RANDS) + bytes([len(modulus)]) + modulus +
+            proof_options_to_bytes(options) +
             write_usize(air.num_assertions() + air.num_transition_constraints()))
 
 

@@ -15,8 +15,11 @@ from .proof import Proof
 from .trace_lde import DefaultTraceLde, StarkDomain
 
 
-def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_elements, timings=None):
+def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_elements, timings=None, build_aux_trace=None):
+    """build_aux_trace(aux_rand_elements) -> ColMatrix over E: Prover::build_aux_trace (prover/src/lib.rs:236-247), the user's
+    builder of the auxiliary trace segment; needed exactly when the AIR is multi-segment."""
     f, ctx, D = air.FIELD, trace.ctx, options.ext_degree
+    assert (build_aux_trace is not None) == air.is_multi_segment(), "a multi-segment AIR comes with Prover::build_aux_trace, the others without"
     assert trace.num_rows() == air.trace_length() and trace.num_cols() == air.TRACE_WIDTH
     tm = timings if timings is not None else {}
 
@@ -31,9 +34,19 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
     trace_lde, trace_polys = DefaultTraceLde.new(hasher, trace, domain)
     channel.commit_trace(trace_lde.get_main_trace_commitment())
     lap("commit_to_main_trace_segment", t0)
+    # 1b. the auxiliary trace segment (lib.rs:320-346): draw its random elements, build it, extend + commit
+    aux_rand_elements = aux_polys = aux_commitment = None
+    if air.is_multi_segment():
+        t0 = time.perf_counter()
+        aux_rand_elements = channel.get_aux_rand_elements()
+        aux_trace = build_aux_trace(aux_rand_elements)
+        assert aux_trace.num_cols() == air.AUX_TRACE_WIDTH and aux_trace.ext_degree == D and aux_trace.num_rows() == air.trace_length()
+        aux_polys, aux_commitment = trace_lde.set_aux_trace(aux_trace, domain)
+        channel.commit_trace(aux_commitment)
+        lap("commit_to_aux_trace_segment", t0)
     # 2. evaluate constraints (lib.rs:353-364)
     t0 = time.perf_counter()
-    evaluator = DefaultConstraintEvaluator(air, channel.get_constraint_composition_coeffs(), D)
+    evaluator = DefaultConstraintEvaluator(air, channel.get_constraint_composition_coeffs(), D, aux_rand_elements=aux_rand_elements)
     composition_poly_trace = evaluator.evaluate(trace_lde, domain)
     lap("evaluate_constraints", t0)
     # 3. commit to the constraint evaluations (lib.rs:366-371, 535-575)
@@ -46,6 +59,8 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
     t0 = time.perf_counter()
     z = channel.get_ood_point()
     table = TracePolyTable(trace_polys)
+    if aux_polys is not None:
+        table.add_aux_segment(aux_polys)                                              # lib.rs:341
     ood_trace_states = table.get_ood_frame(z, D)
     ood_evaluations = composition_poly_ood_frame(composition_poly, z, D)
     channel.send_ood_evaluations(ood_trace_states, ood_evaluations)
@@ -79,4 +94,5 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
                  deep_coefficients=(cc_trace, cc_constraints), fri_layers=fri_layers, fri_remainder=fri_remainder, fri_proof=fri_proof,
                  fri_alphas=channel.fri_alphas, fri_options=fri_options, pow_nonce=channel.pow_nonce, pow_seed=channel.pow_seed, query_positions=query_positions,
                  trace_queries=trace_queries, constraint_queries=constraint_queries, num_composition_columns=composition_poly.num_columns(),
+                 aux_rand_elements=aux_rand_elements, aux_trace_commitment=aux_commitment,
                  timings_ms=tm)
