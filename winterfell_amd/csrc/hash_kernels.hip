@@ -219,9 +219,83 @@ __global__ __launch_bounds__(256) void lde_transpose_hash_kernel(const T *tmp, T
     }
 }
 
+// The same with one row per lane (BLAKE3 family; blowup <= 256): lane (u, ml) loads its row's base_cols values from the coset-major
+// columns (lanes of a coset run along m: contiguous), hashes them out of registers, and only the row-major copy goes through
+// LDS: the workgroup's 256 rows (TM = 256 / b positions x b cosets) are one contiguous 16 KiB (f128: 32 KiB) block of the matrix,
+// staged with 16-byte chunks XOR-swizzled by row and written back 16 bytes per lane in address order.  Against the tile kernel
+// above: no index arithmetic per element, no 8-byte LDS traffic for the hash, 16-byte stores.
+template <class H, int MODE, class T>
+__global__ __launch_bounds__(256) void lde_rows_direct_kernel(const T *tmp, T *lde, uint32_t base_cols, uint32_t log_n, uint32_t log_b, void *leaves) {
+    constexpr int W = sizeof(T) / 8, RW = 8 * W, CP = RW / 2;   // words / 16-byte chunks of a padded row
+    constexpr uint32_t Q = 16 / CP;                              // rows per 256 bytes of LDS (one pass over the banks)
+    __shared__ uint4 stage[256 * CP];
+    const uint64_t n = 1ull << log_n;
+    const uint32_t log_tm = 8 - log_b, TM = 1u << log_tm;
+    const uint32_t tid = threadIdx.x, ml = tid & (TM - 1), u = tid >> log_tm;
+    const uint64_t m0 = (uint64_t)blockIdx.x << log_tm, m = m0 + ml;
+    // Writers are lanes with consecutive ml (rows b apart), readers lanes with consecutive rows: place row r at
+    // r ^ (ml & (Q - 1)) and rotate its chunks by (ml / Q) — sixteen writer lanes and sixteen reader lanes then both touch
+    // sixteen different 16-byte bank groups (log_b >= 1 keeps the row map a bijection: it XORs bits below log2 Q with bits from log_b up)
+    auto phys = [&](uint32_t row, uint32_t c) -> uint32_t {
+        const uint32_t mr = row >> log_b;
+        return (row ^ (mr & (Q - 1))) * CP + (c ^ ((mr / Q) & (CP - 1)));
+    };
+    uint64_t w[RW];
+#pragma unroll
+    for (int i = 0; i < RW; i++) w[i] = 0;
+    if (m < n) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+            if ((uint32_t)c < base_cols) {
+                const T v = tmp[(((uint64_t)c << log_b) + u) * n + m];
+                if constexpr (W == 1) {
+                    w[c] = (uint64_t)v;
+                } else {
+                    w[2 * c] = (uint64_t)v;
+                    w[2 * c + 1] = (uint64_t)(v >> 64);
+                }
+            }
+        }
+        uint32_t d[8];
+        H::template hash_elems<MODE, false>(w, base_cols * W, d);
+        store_digest(leaves, u + (m << log_b), d);
+    }
+    const uint32_t row = (ml << log_b) + u;                       // the lane's row within the workgroup's block
+#pragma unroll
+    for (int c = 0; c < CP; c++)
+        stage[phys(row, c)] = make_uint4((uint32_t)w[2 * c], (uint32_t)(w[2 * c] >> 32), (uint32_t)w[2 * c + 1], (uint32_t)(w[2 * c + 1] >> 32));
+    __syncthreads();
+    if (m0 >= n) return;
+    const uint64_t left = (n - m0) << log_b;                      // rows of the matrix from this block's first row on
+    const uint32_t nv = left < 256 ? (uint32_t)left : 256u;
+    uint4 *out = reinterpret_cast<uint4 *>(lde + (m0 << log_b) * 8);
+#pragma unroll
+    for (int i = 0; i < CP; i++) {
+        const uint32_t L = i * 256 + tid, r = L / CP, cc = L % CP;
+        if (r < nv) out[L] = stage[phys(r, cc)];
+    }
+}
+
 template <class H, class T>
 int launch_lde_transpose_hash(wf_ctx *ctx, int mode, const void *tmp, void *lde, uint32_t base_cols, uint32_t log_n, uint32_t log_b,
                               uint32_t log_tm, void *leaves) {
+    if constexpr (H::WAVE_TREE) {
+        const bool shape_ok = log_b >= 1 && log_b <= 8 && log_n + log_b >= 8 && base_cols <= 8 && (((uint64_t)1 << (log_n + log_b)) >> 8) <= 0x7fffffffull;
+        const bool mode_ok = (sizeof(T) == 8 && mode == MODE_F64_CANON) || (sizeof(T) == 16 && mode == MODE_RAW);
+        if (shape_ok && mode_ok && log_n >= 8 - log_b) {
+            const uint32_t blocks = (uint32_t)(((uint64_t)1 << (log_n + log_b)) >> 8);
+            wf_prof_begin(ctx, "lde_transpose_hash");
+            if constexpr (sizeof(T) == 8)
+                hipLaunchKernelGGL((lde_rows_direct_kernel<H, MODE_F64_CANON, T>), dim3(blocks), dim3(256), 0, ctx->stream, (const T *)tmp, (T *)lde, base_cols,
+                                   log_n, log_b, leaves);
+            else
+                hipLaunchKernelGGL((lde_rows_direct_kernel<H, MODE_RAW, T>), dim3(blocks), dim3(256), 0, ctx->stream, (const T *)tmp, (T *)lde, base_cols,
+                                   log_n, log_b, leaves);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            return WF_OK;
+        }
+    }
     const uint64_t n = 1ull << log_n;
     const uint64_t blocks = (n + (1ull << log_tm) - 1) >> log_tm;
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
