@@ -17,6 +17,7 @@
 // u64, f128 canonical u128 as two u64), extension elements as consecutive base elements.
 #pragma once
 #include <algorithm>
+#include <array>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -469,6 +470,39 @@ inline std::vector<uint64_t> context_to_elements_f64(uint32_t main_width, uint64
             grinding_factor, num_queries};
 }
 
+// crypto::DefaultRandomCoin with its state on the device (wf_coin_*; crypto/src/random/default.rs): the hand-over point between a
+// host coin and a chain of device stages that reseed and draw (FriProver::build_layers below)
+class DeviceCoin {
+  public:
+    DeviceCoin(Context &ctx, Hash h, Field f, const uint8_t seed[32]) : hash_(h), field_(f), state_(ctx, WF_COIN_BYTES) {
+        check(wf_coin_init(ctx.handle(), state_.data(), seed), "wf_coin_init");
+    }
+    // RandomCoin::reseed with a digest that is on the device; the digest is also copied to d_copy when given
+    void reseed(const void *d_digest, void *d_copy = nullptr) {
+        check(wf_coin_reseed(state_.ctx().handle(), (int)hash_, state_.data(), d_digest, d_copy), "wf_coin_reseed");
+    }
+    // `count` x RandomCoin::draw::<E>: count * ext_degree * W words on the device
+    DeviceBuffer draw(uint32_t ext_degree, uint32_t count = 1) {
+        DeviceBuffer out(state_.ctx(), (size_t)count * ext_degree * words(field_) * 8);
+        check(wf_coin_draw(state_.ctx().handle(), (int)hash_, (int)field_, ext_degree, state_.data(), count, out.data()), "wf_coin_draw");
+        return out;
+    }
+    // the state after everything queued so far (waits for the stream); throws if a draw ran out of its 1000 tries
+    std::pair<std::array<uint8_t, 32>, uint64_t> read() const {
+        std::array<uint8_t, 32> seed{};
+        uint64_t counter = 0;
+        check(wf_coin_read(state_.ctx().handle(), state_.data(), seed.data(), &counter), "wf_coin_read");
+        return {seed, counter};
+    }
+    void *state() const { return state_.data(); }
+    Hash hash() const { return hash_; }
+
+  private:
+    Hash hash_;
+    Field field_;
+    DeviceBuffer state_;
+};
+
 // fri::ProverChannel (fri/src/prover/channel.rs:24-50): the host Fiat-Shamir transcript, supplied by the caller
 struct ProverChannel {
     virtual ~ProverChannel() = default;
@@ -521,6 +555,69 @@ class FriProver {
             length = rows;
         }
         set_remainder(channel, evaluations, length);
+    }
+    // The same with the channel's coin on the device (wf_fri_build_layers): every layer's commit, reseed, draw and fold is queued
+    // back to back; what the channel would have recorded comes back at the end — the layer commitments (then the remainder's)
+    // in `roots`, the folding challenges in `alphas` — and the coin has absorbed all of them.
+    struct Transcript {
+        std::vector<std::array<uint8_t, 32>> roots;
+        std::vector<uint64_t> alphas;      // one E element (ext_degree * W words) per layer
+    };
+    Transcript build_layers(DeviceCoin &coin, DeviceBuffer evaluations, uint64_t length) {
+        if (!layers_.empty()) throw std::logic_error("a prior proof generation request has not been completed yet");
+        Context &ctx = evaluations.ctx();
+        const uint32_t ew = D_ * words(field_);
+        const uint64_t N = opts_.folding_factor;
+        const uint32_t nl = (uint32_t)opts_.num_fri_layers(length);
+        Transcript tr;
+        std::vector<DeviceBuffer> transposed, leaves, nodes, folded;
+        std::vector<void *> p_tr, p_lv, p_nd, p_fo;
+        uint64_t rows = length;
+        for (uint32_t k = 0; k < nl; k++) {
+            rows /= N;
+            transposed.emplace_back(ctx, rows * N * ew * 8);
+            leaves.emplace_back(ctx, rows * 32);
+            nodes.emplace_back(ctx, rows * 32);
+            folded.emplace_back(ctx, rows * ew * 8);
+            p_tr.push_back(transposed.back().data());
+            p_lv.push_back(leaves.back().data());
+            p_nd.push_back(nodes.back().data());
+            p_fo.push_back(folded.back().data());
+        }
+        if (nl) {
+            DeviceBuffer d_roots(ctx, (size_t)nl * 32), d_alphas(ctx, (size_t)nl * ew * 8);
+            check(wf_fri_build_layers(ctx.handle(), (int)hash_, (int)field_, D_, evaluations.data(), log2_exact(length, "evaluations"), (uint32_t)N, nl,
+                                      offset_.data(), coin.state(), p_tr.data(), p_lv.data(), p_nd.data(), p_fo.data(), d_roots.data(), d_alphas.data()),
+                  "wf_fri_build_layers");
+            const std::vector<uint8_t> r = d_roots.to_host<uint8_t>();
+            tr.roots.resize(nl);
+            for (uint32_t k = 0; k < nl; k++) std::memcpy(tr.roots[k].data(), &r[(size_t)k * 32], 32);
+            tr.alphas = d_alphas.to_host<uint64_t>();
+            uint64_t rk = length;
+            for (uint32_t k = 0; k < nl; k++) {
+                rk /= N;
+                layers_.push_back(FriLayer{MerkleTree(hash_, std::move(leaves[k]), std::move(nodes[k]), rk), std::move(transposed[k])});
+            }
+            evaluations = std::move(folded[nl - 1]);
+            length = rows;
+        }
+        struct CoinSink : ProverChannel {      // the remainder commitment goes into the device coin as well (mod.rs:230-239)
+            DeviceCoin &coin;
+            Context &ctx;
+            Transcript &tr;
+            CoinSink(DeviceCoin &c, Context &x, Transcript &t) : coin(c), ctx(x), tr(t) {}
+            void commit_fri_layer(const uint8_t root[32]) override {
+                DeviceBuffer d(ctx, root, 32);
+                coin.reseed(d.data());
+                check(wf_ctx_sync(ctx.handle()), "wf_ctx_sync");     // `d` is released when this returns
+                std::array<uint8_t, 32> a{};
+                std::memcpy(a.data(), root, 32);
+                tr.roots.push_back(a);
+            }
+            std::vector<uint64_t> draw_fri_alpha() override { throw std::logic_error("not part of set_remainder"); }
+        } sink(coin, ctx, tr);
+        set_remainder(sink, evaluations, length);
+        return tr;
     }
     const std::vector<FriLayer> &layers() const { return layers_; }
     // fri::folding::fold_positions (fri/src/folding/mod.rs:159-176)
@@ -646,6 +743,38 @@ inline DeviceBuffer evaluate_constraints(int air, const RowMatrix &trace_lde, ui
                                   log2_exact(trace_length, "rows"), log2_exact(lde_blowup, "blowup factor"), log2_exact(ce_blowup, "blowup factor"),
                                   domain_offset, cc_transition.data(), (uint32_t)assertions.size(), cols.data(), steps.data(), vals.data(), cc_boundary.data(),
                                   out.data()), "wf_evaluate_constraints");
+    return out;
+}
+
+// the same for a trace with an auxiliary segment (wf_evaluate_constraints_aux; evaluate_fragment_full, default.rs:214-271):
+// aux assertion values and the segment's random elements are elements of E (ext_degree * W words each); cc_transition = the main
+// constraints' coefficients, then the auxiliary ones; cc_boundary / cc_aux_boundary per assertion.
+inline DeviceBuffer evaluate_constraints_aux(int air, const RowMatrix &main_lde, const RowMatrix &aux_lde, uint64_t trace_length, uint64_t lde_blowup,
+                                             uint64_t ce_blowup, const uint64_t *domain_offset, uint32_t ext_degree,
+                                             const std::vector<uint64_t> &cc_transition, const std::vector<Assertion> &assertions,
+                                             const std::vector<uint64_t> &cc_boundary, const std::vector<Assertion> &aux_assertions,
+                                             const std::vector<uint64_t> &cc_aux_boundary, const std::vector<uint64_t> &aux_rand_elements) {
+    Context &ctx = main_lde.data.ctx();
+    const uint32_t W = words(main_lde.field);
+    std::vector<uint32_t> cols, xcols;
+    std::vector<uint64_t> steps, vals, xsteps, xvals;
+    for (const Assertion &a : assertions) {
+        cols.push_back(a.column);
+        steps.push_back(a.step);
+        vals.insert(vals.end(), a.value.begin(), a.value.begin() + W);
+    }
+    for (const Assertion &a : aux_assertions) {
+        xcols.push_back(a.column);
+        xsteps.push_back(a.step);
+        xvals.insert(xvals.end(), a.value.begin(), a.value.begin() + (size_t)ext_degree * W);
+    }
+    DeviceBuffer out(ctx, trace_length * ce_blowup * ext_degree * 8 * W);
+    check(wf_evaluate_constraints_aux(ctx.handle(), air, (int)main_lde.field, ext_degree, main_lde.data.data(), main_lde.row_width, aux_lde.data.data(),
+                                      aux_lde.row_width, log2_exact(trace_length, "rows"), log2_exact(lde_blowup, "blowup factor"),
+                                      log2_exact(ce_blowup, "blowup factor"), domain_offset, cc_transition.data(), (uint32_t)assertions.size(), cols.data(),
+                                      steps.data(), vals.data(), cc_boundary.data(), (uint32_t)aux_assertions.size(), xcols.data(), xsteps.data(),
+                                      xvals.data(), cc_aux_boundary.data(), aux_rand_elements.data(), out.data()),
+          "wf_evaluate_constraints_aux");
     return out;
 }
 

@@ -289,6 +289,34 @@ int main() {
         or_fri_remainder(0, cur.data(), length, D, offset, blowup, rem.data(), com);
         EXPECT(ok && prover.layers().size() == 3, "FriProver layers: nodes and transposed evaluations");
         EXPECT(prover.remainder_poly() == rem && std::memcmp(chan.commitments.back().data(), com, 32) == 0, "FRI remainder polynomial and its commitment");
+        // the same loop with the coin on the device (wf::DeviceCoin + wf_fri_build_layers): same layers, and the transcript the
+        // oracle channel recorded — every layer root, the remainder commitment, every alpha, the coin's final seed
+        {
+            OracleChannel fresh(0, D);
+            uint8_t seed0[32], seed_end[32];
+            or_coin_seed(fresh.coin.data(), seed0);
+            wf::DeviceCoin dcoin(ctx, wf::Hash::Blake3_256, F, seed0);
+            wf::FriProver fused(wf::FriOptions{blowup, N, 7}, wf::Hash::Blake3_256, F, D, {offset});
+            wf::FriProver::Transcript tr = fused.build_layers(dcoin, wf::DeviceBuffer(ctx, ev), len);
+            bool fok = tr.roots.size() == chan.commitments.size() && fused.layers().size() == prover.layers().size() &&
+                       fused.remainder_poly() == prover.remainder_poly();
+            for (size_t k = 0; fok && k < tr.roots.size(); k++) fok = std::memcmp(tr.roots[k].data(), chan.commitments[k].data(), 32) == 0;
+            std::vector<uint64_t> alphas;
+            OracleChannel replay(0, D);
+            for (size_t k = 0; k + 1 < chan.commitments.size(); k++) {
+                replay.commit_fri_layer(chan.commitments[k].data());
+                const std::vector<uint64_t> a = replay.draw_fri_alpha();
+                alphas.insert(alphas.end(), a.begin(), a.end());
+            }
+            replay.commit_fri_layer(chan.commitments.back().data());
+            or_coin_seed(replay.coin.data(), seed_end);
+            for (size_t k = 0; fok && k < fused.layers().size(); k++)
+                fok = fused.layers()[k].commitment.nodes() == prover.layers()[k].commitment.nodes() &&
+                      fused.layers()[k].evaluations.to_host<uint64_t>() == prover.layers()[k].evaluations.to_host<uint64_t>();
+            const auto st = dcoin.read();
+            EXPECT(fok && tr.alphas == alphas && std::memcmp(st.first.data(), seed_end, 32) == 0 && st.second == 0,
+                   "FriProver::build_layers with a device coin: layers, roots, alphas, coin state");
+        }
         // query phase: rows of every layer at the folded positions, in fold_positions order; build_proof resets the prover
         std::vector<std::vector<uint64_t>> layer_rows;
         for (const auto &l : prover.layers()) layer_rows.push_back(l.evaluations.to_host<uint64_t>());
