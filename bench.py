@@ -141,7 +141,8 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert torch.equal(data, ref), "forward+inverse round trip is not the identity"
+    experiment = os.environ.get("WF_BENCH_TIMING_EXPERIMENT") == "1"       # tools/build_variant.sh builds whose results are wrong by construction
+    assert experiment or torch.equal(data, ref), "forward+inverse round trip is not the identity"
 
     ms_per_step = elapsed * 1e3 / args.steps
     value = 2.0 * n * args.steps * world / elapsed
@@ -155,6 +156,7 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
         "higher_is_better": True,
+        **({"INVALID": "timing experiment: results not checked"} if experiment else {}),
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u64",

@@ -133,6 +133,15 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #endif
     constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * TC * ROW_L : A * ROW_NL);
     __shared__ T lds[LDS_ELEMS];
+    // f64: the intra-pass twiddle rows (four words each, l24.cuh) a workgroup needs — omega_R^(k_a b), R rows — are copied to LDS
+    // once per workgroup: as global loads they were 32 bytes per element through the vector memory pipeline, twice the
+    // pipeline time of the tile's own data (64 B/clk/CU into registers, however few distinct lines the lanes touch).
+#ifndef NTT_W256_IN_LDS
+#define NTT_W256_IN_LDS 1
+#endif
+    constexpr bool WLDS = F::USE_L24 && B > 1 && NTT_W256_IN_LDS != 0;
+    constexpr int WROWS = WLDS ? (1 << LOG_R) : 1;
+    __shared__ uint4 wlds[2 * WROWS];
 
     int tid = threadIdx.x;
     const uint32_t L = p.log_n;
@@ -216,7 +225,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     T x[A];
     bool active;
     uint64_t v1, base1;
+    if constexpr (WLDS) {
+        const uint4 *rows = reinterpret_cast<const uint4 *>(p.w256);
+        for (int i = threadIdx.x; i < 2 * WROWS; i += 256) wlds[i] = rows[2 * ((i >> 1) << (8 - LOG_R)) + (i & 1)];
+    }
     load_inputs(tile, x, active, v1, base1);
+    if constexpr (WLDS) __syncthreads();
     for (;;) {
     log_s = opaque(log_s0);
     if constexpr (PF) {
@@ -265,8 +279,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                 if constexpr (B > 1) {
                     T val;
                     if (ka != 0 || (LAST && p.scale_in_w256)) {
-                        const T *w = p.w256 + 4 * ((uint32_t)(ka * b1) << (8 - LOG_R));
-                        val = l24::fold_lazy(l24::mul4(y, w[0], w[1], w[2], w[3]));
+                        if constexpr (WLDS) {
+                            const uint4 wa = wlds[2 * (ka * b1)], wb = wlds[2 * (ka * b1) + 1];
+                            val = l24::fold_lazy(l24::mul4(y, (T)wa.x | ((T)wa.y << 32), (T)wa.z | ((T)wa.w << 32), (T)wb.x | ((T)wb.y << 32),
+                                                           (T)wb.z | ((T)wb.w << 32)));
+                        } else {
+                            const T *w = p.w256 + 4 * ((uint32_t)(ka * b1) << (8 - LOG_R));
+                            val = l24::fold_lazy(l24::mul4(y, w[0], w[1], w[2], w[3]));
+                        }
                     } else {
                         val = l24::fold_lazy(l24::mul4_one(y));
                     }
@@ -298,12 +318,27 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     const int t2 = (B > 1) ? tid % TC : t1;
     const int q2 = (B > 1) ? tid / TC : 0;
     const uint64_t cc = cc0 + t2;
-    // the next tile's loads go out now: they stay in flight through the whole of step 2
     const uint64_t next_tile = tile + gridDim.x;
     const bool more = PF && next_tile < ntiles;
     T xn[A];
     bool active_n = false;
     uint64_t vn = 0, basen = 0;
+    // The prefetching variants run on whole tiles only (cc < total_cols for every lane).  The memory counter of a wavefront
+    // retires in order: any load that step 2 issued AFTER the prefetch would make its wait drain the prefetch too.  So the only
+    // loads of step 2 — the (base, step) look-ups of the twiddle progressions — are taken first, then the next tile's loads go
+    // out and stay in flight through the whole of step 2 (which from here on touches registers and LDS only).
+    T pf_cur[G > 0 ? G : 1], pf_stp[G > 0 ? G : 1];
+    if constexpr (PF && !LAST && B > 1) {
+        uint64_t v0, c0;
+        uint32_t bq, uq;
+        decompose(cc, v0, c0, bq, uq);
+        const uint32_t r32 = (uint32_t)(c0 & ((1ull << log_s) - 1));
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            pf_cur[g] = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, ((uint32_t)(q2 + B * g) * r32) << log_mult);
+            pf_stp[g] = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, ((uint32_t)A * r32) << log_mult);
+        }
+    }
     if (more) load_inputs(next_tile, xn, active_n, vn, basen);
     if (cc < total_cols) {
     uint64_t v, c;
@@ -343,7 +378,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     // replace a two-level look-up per output: 2 + (CNT - 1) + CNT multiplications instead of 2 (CNT - 1), but 4 loads
     // instead of 2 CNT and none of the per-output index arithmetic.
     // `val(i)` yields the value in register i (for f64 it leaves the limb representation on demand, one element at a time)
-    auto emit_progression = [&](auto &&val, uint32_t k0, uint32_t step_k, auto log_cnt_tag) {
+    auto emit_progression = [&](auto &&val, uint32_t k0, uint32_t step_k, auto log_cnt_tag, int g = 0) {
         constexpr int LOG_CNT = decltype(log_cnt_tag)::value;
         constexpr int CNT = 1 << LOG_CNT;
         const uint32_t r32 = (uint32_t)rem;
@@ -358,8 +393,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             }
             return;
         }
-        T cur = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (k0 * r32) << log_mult);
-        const T stp = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (step_k * r32) << log_mult);
+        T cur, stp;
+        if constexpr (PF && B > 1) {
+            cur = pf_cur[g];
+            stp = pf_stp[g];
+        } else {
+            cur = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (k0 * r32) << log_mult);
+            stp = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, (step_k * r32) << log_mult);
+        }
 #pragma unroll
         for (int ip = 0; ip < CNT; ip++) {
             const int i = brev(ip, LOG_CNT);                 // register holding output digit ip
@@ -422,7 +463,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                         return LAST ? l24::fold(l24::mul4_one(yl)) : l24::fold_lazy(l24::mul4_one(yl));
                     };
                     if constexpr (!LAST) {
-                        emit_progression(out, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
+                        emit_progression(out, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{}, g);
                     } else {
 #pragma unroll
                         for (int i = 0; i < B; i++) emit(out(i), (uint32_t)(ka + A * brev(i, LOG_B)));
