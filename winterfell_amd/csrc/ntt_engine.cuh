@@ -227,6 +227,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     uint64_t v1, base1;
     if constexpr (WLDS) {
         const uint4 *rows = reinterpret_cast<const uint4 *>(p.w256);
+        // rows at their natural place, the two 16-byte halves of a row next to each other (a [half][k_a][b] layout that is free of
+        // bank conflicts for the last pass's lanes measured SLOWER: 73 against 64 us for that pass)
         for (int i = threadIdx.x; i < 2 * WROWS; i += 256) wlds[i] = rows[2 * ((i >> 1) << (8 - LOG_R)) + (i & 1)];
     }
     load_inputs(tile, x, active, v1, base1);
@@ -578,6 +580,12 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
     // (radix 2) have no limb form of the table multiplication
     const uint32_t max_log = F::USE_L24 ? NTT_TW_TABLE_MAX_LOG - 1 : NTT_TW_TABLE_MAX_LOG;
     if (NTT_TW_TABLE_MAX_LOG == 0 || log_total > max_log || (F::USE_L24 && log_b_for(r) == 0)) return WF_OK;
+    // f64: 32 bytes of table per element through the vector memory pipeline cost what the 15-multiplication chain costs in issue
+    // slots (passes of a 2^24 transform: 75.9 against 73.6-76.6 us): the per-lane progression is used throughout unless a build asks
+    // for the tables (-DNTT_F64_TW_TABLES); f128 / f62 keep them (-7 % on their passes)
+#ifndef NTT_F64_TW_TABLES
+    if (F::USE_L24) return WF_OK;
+#endif
     auto key = std::make_tuple((int)F::ID, L, r, log_s, log_mult);
     auto it = ctx->pass_twiddles.find(key);
     if (it == ctx->pass_twiddles.end()) {
