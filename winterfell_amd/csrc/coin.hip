@@ -118,8 +118,83 @@ __global__ void coin_reseed_draw_kernel(CoinState *c, const uint32_t *digest, ui
     c->counter = counter;
 }
 
+// The same for Blake3_256 on FOUR lanes (b3::quad_hash_block): the two compressions of a reseed + draw are the whole kernel, and
+// each is ~300 dependent instructions on a quad instead of ~800 on one lane.  Messages go through LDS (seed || digest, then
+// seed' || counter); lane 0 decodes the drawn bytes.
+template <int FIELD, int D>
+__global__ __launch_bounds__(64) void coin_reseed_draw_quad_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out, uint64_t *out) {
+    __shared__ uint32_t msg[16], drawn[8];
+    __shared__ int ok_flag;
+    const uint32_t q = threadIdx.x;
+    if (q < 4) {
+        msg[q] = c->seed[q];
+        msg[4 + q] = c->seed[4 + q];
+        msg[8 + q] = digest[q];
+        msg[12 + q] = digest[4 + q];
+        if (root_out) {
+            root_out[q] = digest[q];
+            root_out[4 + q] = digest[4 + q];
+        }
+    }
+    __syncthreads();
+    uint32_t lo = 0, hi = 0;
+    if (q < 4) {
+        const b3::Quad k = b3::quad_init(q, 64, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);     // merge: 64 bytes
+        b3::quad_hash_block(k, msg, lo, hi);
+        c->seed[q] = lo;
+        c->seed[4 + q] = hi;
+    }
+    const b3::Quad k40 = b3::quad_init(q & 3, 40, b3::CHUNK_START | b3::CHUNK_END | b3::ROOT);   // merge_with_int: seed || u64
+    uint64_t counter = 0;
+    bool ok = false;
+    for (int tries = 0; tries < 1000 && !ok; tries++) {
+        counter++;
+        __syncthreads();
+        if (q < 4) {
+            msg[q] = lo;
+            msg[4 + q] = hi;
+            msg[8 + q] = q == 0 ? (uint32_t)counter : q == 1 ? (uint32_t)(counter >> 32) : 0u;
+            msg[12 + q] = 0;
+        }
+        __syncthreads();
+        if (q < 4) {
+            uint32_t dl, dh;
+            b3::quad_hash_block(k40, msg, dl, dh);
+            drawn[q] = dl;
+            drawn[4 + q] = dh;
+        }
+        __syncthreads();
+        if (q == 0) {
+            uint32_t b[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) b[i] = drawn[i];
+            ok_flag = coin_element<FIELD, D>(b, out) ? 1 : 0;
+        }
+        __syncthreads();
+        ok = ok_flag != 0;
+    }
+    if (q == 0) {
+        if (!ok) c->failed = 1;
+        c->counter = counter;
+    }
+}
+
 template <class H>
 int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, const uint32_t *dg, uint32_t *cp, uint64_t *o) {
+    if constexpr (H::QUAD_MERGE) {
+#define WF_RQ(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_quad_kernel<FIELD, DEG>), dim3(1), dim3(64), 0, ctx->stream, c, dg, cp, o)
+        if (field == WF_FIELD_F128) {
+            if (D == 1) WF_RQ(WF_FIELD_F128, 1);
+            else WF_RQ(WF_FIELD_F128, 2);
+            return WF_OK;
+        } else if (field == WF_FIELD_F64) {
+            if (D == 1) WF_RQ(WF_FIELD_F64, 1);
+            else if (D == 2) WF_RQ(WF_FIELD_F64, 2);
+            else WF_RQ(WF_FIELD_F64, 3);
+            return WF_OK;
+        }
+#undef WF_RQ
+    }
 #define WF_RD(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_kernel<H, FIELD, DEG>), dim3(1), dim3(1), 0, ctx->stream, c, dg, cp, o)
     if (field == WF_FIELD_F128) {
         if (D == 1) WF_RD(WF_FIELD_F128, 1);

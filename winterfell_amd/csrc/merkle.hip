@@ -7,8 +7,11 @@ namespace {
 // One stage of the tree: `count` input digests (a power of two), each workgroup reduces a chunk of
 // CH = min(count, 1024) of them through log2(CH) levels.  Level d of the stage has count >> (d+1) nodes that
 // live at heap indices [count >> (d+1), count >> d) of `nodes`.
-template <class H>
-__global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void *nodes, uint64_t count, uint32_t log_ch) {
+// THREADS = 1024 for launches of at most 256 workgroups (the chip is not full anyway): level 0 is then one compression deep
+// instead of two, and the four-lane levels start at 256 merges instead of 128 — these launches are chains of dependent
+// compressions, their cost is their depth.
+template <class H, int THREADS = 256>
+__global__ __launch_bounds__(THREADS) void merkle_stage_kernel(const void *in, void *nodes, uint64_t count, uint32_t log_ch) {
     __shared__ uint4 bufA[512 * 2];
     __shared__ uint4 bufB[256 * 2];
     const uint32_t ch = 1u << log_ch;
@@ -17,7 +20,7 @@ __global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void 
     // level 0: from global
     {
         const uint32_t cnt = ch >> 1;
-        for (uint32_t i = tid; i < cnt; i += 256) {
+        for (uint32_t i = tid; i < cnt; i += THREADS) {
             uint32_t m[16], d[8];
             load_pair(in, wg * cnt + i, m);
             H::merge(m, d);
@@ -34,10 +37,10 @@ __global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void 
         const uint32_t cnt = ch >> (lvl + 1);
         if constexpr (H::QUAD_MERGE) {
             // the thin levels: a merge per FOUR lanes (blake3.cuh quad_hash_block) — a level is one short compression deep
-            // instead of one long one, and up to 128 merges still fit the workgroup's four wavefronts in two steps
-            if (cnt <= 128) {
+            // instead of one long one, and up to THREADS / 2 merges still fit the workgroup's wavefronts in two steps
+            if (cnt <= THREADS / 2) {
                 const uint32_t q = tid & 3;
-                for (uint32_t i = tid >> 2; i < cnt; i += 64) {
+                for (uint32_t i = tid >> 2; i < cnt; i += THREADS / 4) {
                     uint32_t lo, hi;
                     b3::quad_hash_block(quad, reinterpret_cast<const uint32_t *>(src + 4 * i), lo, hi);
                     uint32_t *node = reinterpret_cast<uint32_t *>(nodes) + ((count >> (lvl + 1)) + wg * cnt + i) * 8;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void merkle_stage_kernel(const void *in, void 
                 continue;
             }
         }
-        for (uint32_t i = tid; i < cnt; i += 256) {
+        for (uint32_t i = tid; i < cnt; i += THREADS) {
             uint32_t m[16], d[8];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
@@ -313,8 +316,14 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
         const uint64_t wgs = count >> log_ch;
         if (wgs > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
         wf_prof_begin(ctx, H::merkle_name());
-        hipLaunchKernelGGL(merkle_stage_kernel<H>, dim3((uint32_t)wgs), dim3(256), 0, ctx->stream, (const void *)in, nodes,
-                           count, log_ch);
+        bool wide = false;
+        if constexpr (H::QUAD_MERGE) {
+            if (wgs <= 256) {
+                wide = true;
+                hipLaunchKernelGGL((merkle_stage_kernel<H, 1024>), dim3((uint32_t)wgs), dim3(1024), 0, ctx->stream, (const void *)in, nodes, count, log_ch);
+            }
+        }
+        if (!wide) hipLaunchKernelGGL((merkle_stage_kernel<H, 256>), dim3((uint32_t)wgs), dim3(256), 0, ctx->stream, (const void *)in, nodes, count, log_ch);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
         count = wgs;
