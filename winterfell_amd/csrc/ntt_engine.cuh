@@ -25,6 +25,8 @@
 //
 // HBM traffic: P reads + P writes of the data (P = 3 at n = 2^24), see DESIGN.md.
 #pragma once
+#include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <type_traits>
@@ -533,8 +535,33 @@ inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
 // 64-bit fields; f128 uses 6: a radix-256 pass of 16-byte elements needs 207 VGPRs and 70 KB of LDS per workgroup
 // (2 waves per SIMD), a radix-64 pass 116 VGPRs and 35 KB (4 waves per SIMD), which more than pays for the extra pass.
 static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, uint32_t log_r[6]) {
+    // WF_NTT_PLAN="L:r0,r1,...": a pass plan for transforms of 2^L points (tools/time_batch_ntt.py measures alternatives with it)
+    if (const char *env = getenv("WF_NTT_PLAN")) {
+        unsigned l = 0, r[6] = {0, 0, 0, 0, 0, 0};
+        const int got = sscanf(env, "%u:%u,%u,%u,%u,%u,%u", &l, &r[0], &r[1], &r[2], &r[3], &r[4], &r[5]);
+        if (got >= 2 && l == L) {
+            uint32_t sum = 0, k = 0;
+            for (; k < 6 && r[k]; k++) sum += r[k] <= max_bits ? r[k] : 1000;
+            if (sum == L) {
+                npass = k;
+                for (uint32_t q = 0; q < 6; q++) log_r[q] = r[q];
+                return;
+            }
+        }
+    }
     npass = (L + max_bits - 1) / max_bits;
     if (npass == 0) npass = 1;
+    if (npass == 3 && max_bits == 8 && L >= 18) {
+        // three radix <= 256 passes: the widest in the middle, the rest split evenly with the first pass the larger one — measured over
+        // every split of 2^18 .. 2^23 points (tools/time_batch_ntt.py with WF_NTT_PLAN): 2^20: 6,8,6 417 us against 7,7,6 436 and
+        // 7,6,7 474 for 32 vectors; 2^19: 6,7,6 403 against 7,6,6 426; 2^23: 8,8,7 437 against 7,8,8 449
+        const uint32_t mid = L - 12 < 8 ? L - 12 : 8, rest = L - mid;
+        log_r[0] = (rest + 1) / 2;
+        log_r[1] = mid;
+        log_r[2] = rest / 2;
+        for (uint32_t q = 3; q < 6; q++) log_r[q] = 0;
+        return;
+    }
     uint32_t rem = L;
     for (uint32_t q = 0; q < npass; q++) {
         uint32_t left = npass - q;
