@@ -466,9 +466,15 @@ def main():
                 t1 = time.perf_counter()
                 oracle.merkle_build(0, lvh, par=True)
                 cpu["merkle_blake3_leaves_per_s_2^23"] = (1 << 23) / (time.perf_counter() - t1)
+                # FRI commit phase (fri/benches/prover.rs shape of the GPU number above): all cores, DefaultProverChannel
+                evh = rng.integers(0, fields.M, (1 << 24) * 2, dtype=np.uint64)
+                t1 = time.perf_counter()
+                oracle.fri_build_layers_par(0, evh, 4, 8, 31, fields.new(7), 2)
+                cpu["fri_build_layers_ms_2^24_quad_fold4_blake3"] = (time.perf_counter() - t1) * 1e3
+                del evh
                 cpu["extras_note"] = ("one call each (buffers allocated inside the call); concurrent interpolate_columns + 8-column-segment "
-                                      "LDE + commit_to_rows + subtree-per-thread Merkle (oracle/commit.c), portable-C BLAKE3 (the Rust "
-                                      "crate is AVX2/AVX-512)")
+                                      "LDE + commit_to_rows + subtree-per-thread Merkle (oracle/commit.c), FRI layers with parallel transpose / "
+                                      "row hashing / folding (oracle/fri.c), portable-C BLAKE3 (the Rust crate is AVX2/AVX-512)")
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
 

@@ -338,6 +338,21 @@ def apply_drp(transposed, N, domain_offset, alpha, D=1):
     return out
 
 
+def fri_build_layers_par(hasher, evals, N, blowup, remainder_max_degree, domain_offset, D=1):
+    """FriProver::build_layers on all cores (the reference's `concurrent` feature) against a DefaultProverChannel.
+    Returns (roots (layers + 1, 32), alphas (layers, D)); `evals` is copied."""
+    v = _u64arr(evals).copy()
+    length = v.size // D
+    nl = fri_num_layers(length, N, blowup, remainder_max_degree)
+    roots = np.empty((nl + 1, 32), dtype=np.uint8)
+    alphas = np.empty((max(nl, 1), D), dtype=np.uint64)
+    lib().or_fri_build_layers_par.restype = _u64
+    got = lib().or_fri_build_layers_par(ctypes.c_int(hasher), _ptr(v), _u64(length), ctypes.c_uint(D), _u64(N), _u64(blowup),
+                                        _u64(remainder_max_degree), _u64(domain_offset), _ptr(roots), _ptr(alphas))
+    assert int(got) == nl
+    return roots, alphas[:nl]
+
+
 def apply_drp_rows(transposed, N, domain_size, row_start, domain_offset, alpha, D=1):
     """apply_drp for a contiguous range of rows of a layer with `domain_size` points (multi-GPU shard)."""
     v = _u64arr(transposed)

@@ -21,6 +21,7 @@ void or_hash_elements(int hasher, const uint64_t *elems, uint64_t n, uint8_t dig
 void or_hash_merge(int hasher, const uint8_t two[64], uint8_t digest[32]);
 void or_hash_merge_with_int(int hasher, const uint8_t seed[32], uint64_t value, uint8_t digest[32]);
 int or_merkle_build(int hasher, const uint8_t *leaves, uint64_t n_leaves, uint8_t *nodes);
+int or_merkle_build_par(int hasher, const uint8_t *leaves, uint64_t n_leaves, uint8_t *nodes);
 void or_f64_get_inv_twiddles(uint64_t *out, uint64_t n);
 void or_f64_fft_in_place(uint64_t *values, uint64_t n, unsigned D, const uint64_t *twiddles);
 void or_f64_permute(uint64_t *v, uint64_t n, unsigned D);
@@ -186,3 +187,71 @@ uint64_t or_coin_draw_integers(or_coin *c, uint64_t num_values, uint64_t domain_
     return n;
 }
 void or_coin_seed(const or_coin *c, uint8_t out[32]) { memcpy(out, c->seed, 32); }
+
+
+/* FriProver::build_layers with the reference's `concurrent` feature (fri/src/prover/mod.rs:179-239: transpose_slice and
+ * build_layer_commitment batch their rows over the thread pool, utils/core/src/lib.rs:185-203; apply_drp maps rows in parallel,
+ * fri/src/folding/mod.rs:101-117; the Merkle tree builds one subtree per thread) against a DefaultProverChannel: the CPU side of
+ * the FRI number in bench.py.  evals (len * D words) is consumed.  roots: one per layer + the remainder commitment; returns the
+ * number of layers.  Same values as the serial functions above (tests/test_oracle_f64.py). */
+uint64_t or_fri_build_layers_par(int hasher, uint64_t *evals, uint64_t len, unsigned D, uint64_t N, uint64_t blowup, uint64_t remainder_max_degree,
+                                 uint64_t domain_offset, uint8_t *roots, uint64_t *alphas) {
+    or_coin coin;
+    or_coin_new(&coin, hasher, NULL, 0);
+    const uint64_t nl = or_fri_num_layers(len, N, blowup, remainder_max_degree);
+    uint64_t *cur = evals, *tr = (uint64_t *)malloc(len * D * 8), *folded = (uint64_t *)malloc((len / N) * D * 8);
+    uint8_t *leaves = (uint8_t *)malloc((len / N) * 32), *nodes = (uint8_t *)malloc((len / N) * 32);
+    uint64_t *inv_tw = (uint64_t *)malloc((N / 2 ? N / 2 : 1) * 8);
+    or_f64_get_inv_twiddles(inv_tw, N);
+    const uint64_t len_offset = f64_inv(f64_new((uint32_t)N)), off_inv = f64_inv(domain_offset);
+    for (uint64_t k = 0; k < nl; k++) {
+        const uint64_t rc = len / N;
+#pragma omp parallel for schedule(static)
+        for (uint64_t i = 0; i < rc; i++) {
+            for (uint64_t j = 0; j < N; j++) memcpy(tr + (i * N + j) * D, cur + (i + j * rc) * D, D * 8);
+            or_hash_elements(hasher, tr + i * N * D, N * D, leaves + 32 * i);
+        }
+        or_merkle_build_par(hasher, leaves, rc, nodes);
+        memcpy(roots + 32 * k, nodes + 32, 32);
+        or_coin_reseed(&coin, nodes + 32);
+        uint64_t alpha[3];
+        if (or_coin_draw(&coin, D, alpha)) return ~0ull;
+        memcpy(alphas + k * D, alpha, D * 8);
+        const uint64_t g_inv = f64_inv(f64_root_of_unity((unsigned)__builtin_ctzll(len)));
+#pragma omp parallel
+        {
+            uint64_t poly[16 * 3], io = 0;
+            int have = 0;
+#pragma omp for schedule(static)
+            for (uint64_t i = 0; i < rc; i++) {
+                if (!have) { io = f64_mul(off_inv, f64_exp(g_inv, i)); have = 1; }      /* a thread's rows are consecutive */
+                memcpy(poly, tr + i * N * D, N * D * 8);
+                or_f64_fft_in_place(poly, N, D, inv_tw);
+                or_f64_permute(poly, N, D);
+                uint64_t offset = len_offset;
+                for (uint64_t q = 0; q < N; q++) {
+                    for (unsigned d = 0; d < D; d++) poly[q * D + d] = f64_mul(poly[q * D + d], offset);
+                    offset = f64_mul(offset, io);
+                }
+                uint64_t acc[3] = {f64_new(0), f64_new(0), f64_new(0)}, t[3];
+                for (uint64_t q = N; q-- > 0;) {
+                    f64_extD_mul(D, acc, alpha, t);
+                    for (unsigned d = 0; d < D; d++) acc[d] = f64_add(t[d], poly[q * D + d]);
+                }
+                memcpy(folded + i * D, acc, D * 8);
+                io = f64_mul(io, g_inv);
+            }
+        }
+        memcpy(cur, folded, rc * D * 8);
+        len = rc;
+    }
+    uint64_t *rem = (uint64_t *)malloc((len / blowup ? len / blowup : 1) * D * 8);
+    or_fri_remainder(hasher, cur, len, D, domain_offset, blowup, rem, roots + 32 * nl);
+    free(rem);
+    free(inv_tw);
+    free(nodes);
+    free(leaves);
+    free(folded);
+    free(tr);
+    return nl;
+}

@@ -145,3 +145,26 @@ def test_fused_layer_loop_equals_the_layer_by_layer_prover(wf, hname, fname, D, 
     assert np.array_equal(pa.remainder_poly, pb.remainder_poly)
     assert np.array_equal(ca.public_coin.seed, cb.public_coin.seed) and ca.public_coin.counter == cb.public_coin.counter
     assert ca.draw_query_positions(3) == cb.draw_query_positions(3)
+
+
+def test_fused_layer_loop_with_a_rescue_hasher(wf, monkeypatch):
+    """the library call works for every hasher; the Python prover only skips it for the Rescue family because a single-lane
+    permutation is slower than the round trip it saves (crypto/hash.py DEVICE_COIN) — forced on here"""
+    ctx, crypto, fri, fields = wf
+    f = fields.f64
+    monkeypatch.setattr(crypto.Rp64_256, "DEVICE_COIN", True)
+    n, D, N = 1 << 10, 2, 4
+    rng = np.random.default_rng(77)
+    ev = f.from_ints([int(v) % f.M for v in rng.integers(0, 1 << 63, n * D, dtype=np.uint64)])
+    opts = fri.FriOptions(8, N, 7, field=f)
+    runs = []
+    for device_coin in (True, False):
+        chan = fri.DefaultProverChannel(n, 8, crypto.Rp64_256, ext_degree=D, field=f, ctx=ctx, device_coin=device_coin)
+        pr = fri.FriProver(opts, crypto.Rp64_256, ext_degree=D, ctx=ctx)
+        pr.build_layers(chan, ev.copy())
+        runs.append((chan, pr))
+    (ca, pa), (cb, pb) = runs
+    assert ca.fri_device_coin() is not None and cb.fri_device_coin() is None
+    assert len(ca.commitments) == len(cb.commitments) and all(np.array_equal(x, y) for x, y in zip(ca.commitments, cb.commitments))
+    assert all(np.array_equal(x, y) for x, y in zip(ca.alphas, cb.alphas)) and np.array_equal(pa.remainder_poly, pb.remainder_poly)
+    assert np.array_equal(ca.public_coin.seed, cb.public_coin.seed)

@@ -1,7 +1,9 @@
 """Pin the CPU oracle (oracle/) against the reference's fixed vectors and independent derivations."""
 import numpy as np
 
-from conftest import P, splitmix64
+import pytest
+
+from conftest import P, rand_field, splitmix64
 
 
 def test_field_edge_cases(oracle, golden):
@@ -103,3 +105,28 @@ def test_extension_ntt_is_componentwise(oracle):
     ev = oracle.evaluate_poly(p.reshape(-1), D=3).reshape(n, 3)
     for d in range(3):
         assert np.array_equal(ev[:, d], oracle.evaluate_poly(np.ascontiguousarray(p[:, d])))
+
+
+@pytest.mark.parametrize("hasher,D,log_len,N,rem_deg", [(0, 2, 14, 4, 31), (0, 1, 12, 2, 7), (1, 3, 11, 8, 3), (0, 2, 10, 16, 7)])
+def test_parallel_fri_driver_equals_the_serial_functions(oracle, hasher, D, log_len, N, rem_deg):
+    """or_fri_build_layers_par (the all-cores CPU side of bench.py's FRI number) against the serial restatement layer by layer
+    with an independent DefaultProverChannel: every root, every alpha, the remainder commitment."""
+    blowup, n = 8, 1 << log_len
+    poly = oracle.f64_from_int(rand_field(50 + log_len + N, (n // blowup) * D))
+    ev = oracle.evaluate_poly_with_offset(poly, oracle.f64_new(7), blowup, D=D, par=True)
+    roots, alphas = oracle.fri_build_layers_par(hasher, ev, N, blowup, rem_deg, oracle.f64_new(7), D)
+    chan = oracle.ProverChannel(hasher, D)
+    cur, length = ev.copy(), n
+    nl = int(oracle.fri_num_layers(n, N, blowup, rem_deg))
+    assert roots.shape[0] == nl + 1 and alphas.shape[0] == nl
+    for k in range(nl):
+        tr = oracle.transpose_slice(cur, N, D)
+        _, nodes = oracle.fri_layer_commit(hasher, tr, N, D)
+        assert np.array_equal(nodes[1], roots[k]), "layer %d root" % k
+        chan.commit_fri_layer(nodes[1])
+        alpha = chan.draw_fri_alpha()
+        assert np.array_equal(alpha, alphas[k]), "layer %d alpha" % k
+        cur = oracle.apply_drp(tr, N, oracle.f64_new(7), alpha, D)
+        length //= N
+    _, com = oracle.fri_remainder(hasher, cur, oracle.f64_new(7), blowup, D)
+    assert np.array_equal(com, roots[nl])
