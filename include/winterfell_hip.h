@@ -333,19 +333,23 @@ int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, c
 int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                      uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded);
 
-/* FriProver::build_layers' loop (fri/src/prover/mod.rs:179-199) against a device-resident coin: for each of the
- * num_layers layers  build_layer = commit (as wf_fri_layer_commit), channel.commit_fri_layer(root) = coin.reseed(root),
+/* FriProver::build_layers (fri/src/prover/mod.rs:179-239) against a device-resident coin: for each of the num_layers layers
+ * build_layer = commit (as wf_fri_layer_commit), channel.commit_fri_layer(root) = coin.reseed(root),
  * alpha = channel.draw_fri_alpha() = coin.draw::<E>(), apply_drp (as wf_fri_apply_drp) — queued back to back on the
- * context's stream, nothing waits on the host.  Layer k (k = 0 .. num_layers-1) works on 2^log_len / folding^k points:
+ * context's stream, nothing waits on the host (a layer's fold and the next layer's transpose + leaf hashes are one launch
+ * where a fused kernel exists).  Layer k (k = 0 .. num_layers-1) works on 2^log_len / folding^k points:
  *   d_transposed[k], d_leaves[k], d_nodes[k]   OUT  the layer's evaluations / row digests / Merkle nodes (kept for the query phase)
- *   d_folded[k]                                OUT  the next layer's evaluations (d_folded[num_layers-1] is the remainder's input)
- *   d_roots   OUT num_layers x 32 bytes, d_alphas OUT num_layers x ext_degree elements (what the channel would have seen)
- * The four pointer arrays are host arrays of device pointers.  The caller reads roots / alphas / the coin back once,
- * after the loop (the remainder commitment, mod.rs:230-239, is its next step). */
+ *   d_folded[k]                                OUT  the next layer's evaluations
+ *   d_roots   OUT (num_layers + 1) x 32 bytes, d_alphas OUT num_layers x ext_degree elements (what the channel would have seen)
+ * The four pointer arrays are host arrays of device pointers.  With d_remainder != NULL the remainder step (set_remainder,
+ * mod.rs:230-239) follows on the stream: the last evaluations (d_folded[num_layers-1], or d_evals when there is no layer —
+ * overwritten) are interpolated over the coset, the first len / blowup coefficients go to d_remainder in reverse order, their
+ * hash_elements digest to d_roots[num_layers] and into the coin.  d_remainder == NULL: the caller does that step (blowup unused).
+ * The caller reads roots / alphas / remainder / the coin back once, after the call. */
 int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_len,
                         uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
                         void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded,
-                        void *d_roots, void *d_alphas);
+                        void *d_roots, void *d_alphas, uint32_t blowup, void *d_remainder);
 
 /* The same fold for `num_rows` consecutive rows, starting at row_start, of a layer whose full domain has 2^log_len
  * points: d_transposed_rows holds only those rows, d_folded receives num_rows elements.  This is what one GPU runs on

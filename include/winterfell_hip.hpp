@@ -585,9 +585,10 @@ class FriProver {
             p_fo.push_back(folded.back().data());
         }
         if (nl) {
-            DeviceBuffer d_roots(ctx, (size_t)nl * 32), d_alphas(ctx, (size_t)nl * ew * 8);
+            DeviceBuffer d_roots(ctx, (size_t)(nl + 1) * 32), d_alphas(ctx, (size_t)nl * ew * 8);
             check(wf_fri_build_layers(ctx.handle(), (int)hash_, (int)field_, D_, evaluations.data(), log2_exact(length, "evaluations"), (uint32_t)N, nl,
-                                      offset_.data(), coin.state(), p_tr.data(), p_lv.data(), p_nd.data(), p_fo.data(), d_roots.data(), d_alphas.data()),
+                                      offset_.data(), coin.state(), p_tr.data(), p_lv.data(), p_nd.data(), p_fo.data(), d_roots.data(), d_alphas.data(),
+                                      0, nullptr),     // the remainder step below goes through this class's own set_remainder
                   "wf_fri_build_layers");
             const std::vector<uint8_t> r = d_roots.to_host<uint8_t>();
             tr.roots.resize(nl);

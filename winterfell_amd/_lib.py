@@ -64,7 +64,7 @@ _PROTOS = {
     "wf_fri_layer_commit": [_vp, _int, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp, _vp],
     "wf_fri_apply_drp": [_vp, _int, _u32, _vp, _u32, _u32, _vp, _vp, _vp],
     "wf_fri_apply_drp_rows": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
-    "wf_fri_build_layers": [_vp, _int, _int, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "wf_fri_build_layers": [_vp, _int, _int, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _u32, _vp],
     "wf_coin_init": [_vp, _vp, _vp],
     "wf_coin_reseed": [_vp, _int, _vp, _vp, _vp],
     "wf_coin_draw": [_vp, _int, _int, _u32, _vp, _u32, _vp],

@@ -51,6 +51,14 @@ class DefaultRandomCoin:
         self.counter = 0
         self._ahead = []            # as_bytes of merge_with_int(seed, counter + 1 + k): a run of counters is ONE device batch
 
+    @classmethod
+    def from_seed(cls, hasher, field, seed_digest, ctx=None):
+        """a coin whose seed digest is already known (e.g. the digest of the empty seed, the same for every proof)"""
+        c = cls.__new__(cls)
+        c.hasher, c.field, c.ctx = hasher, field, ctx
+        c.seed, c.counter, c._ahead = np.array(seed_digest, dtype=np.uint8, copy=True), 0, []
+        return c
+
     def reseed(self, data):
         """seed = merge(seed, data); counter = 0 (:150-153)"""
         self.seed = self.hasher.merge(np.stack([self.seed, np.asarray(data, dtype=np.uint8).reshape(32)]), self.ctx)
@@ -135,7 +143,11 @@ class DeviceCoin:
 
     def move_to(self, d_state):
         """keep the state in the caller's 64 device bytes (so that it comes back with the caller's own read)"""
-        d_state.copy_(self.ctx.to_device(self._image) if self.state is None else self.state)
+        if self.state is None:
+            import torch
+            d_state.copy_(torch.from_numpy(self._image))         # one host-to-device copy straight into the caller's bytes
+        else:
+            d_state.copy_(self.state)
         self.state = d_state
 
     def set_host_image(self, image):

@@ -9,7 +9,7 @@
 // (wf_fri_layer_commit / wf_fri_apply_drp), or the coin lives on the device and wf_fri_build_layers queues the whole loop.
 #include <string.h>
 
-#include "dft_regs.cuh"
+#include "fri_fold.cuh"
 #include "tables.cuh"
 #include "wf_internal.h"
 
@@ -26,6 +26,15 @@ __global__ __launch_bounds__(256) void fri_transpose_kernel(const T *ev, T *out,
 #pragma unroll
         for (int d = 0; d < D; d++) out[(i * N + j) * D + d] = ev[(i + (uint64_t)j * rc) * D + d];
     }
+}
+
+// set_remainder (mod.rs:230-239): the first `size` coefficients in reverse order
+template <class T>
+__global__ __launch_bounds__(256) void reverse_prefix_kernel(const T *src, T *dst, uint32_t size, uint32_t ew) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= size * ew) return;
+    const uint32_t e = i / ew, w = i - e * ew;
+    dst[i] = src[(size - 1 - e) * ew + w];
 }
 
 template <class T>
@@ -48,25 +57,11 @@ __global__ __launch_bounds__(256) void fri_fold_kernel(const typename F::T *t, t
     for (int j = 0; j < N; j++)
 #pragma unroll
         for (int d = 0; d < D; d++) comp[d][j] = F::load_norm(t[(i * N + j) * D + d]);
-    // forward DFT per component (bit-reversed registers); inverse coefficient k = X[(N - k) mod N]
-#pragma unroll
-    for (int d = 0; d < D; d++) dft_dif<F, LOG_NF>(comp[d], w16);
     const T io = series_at<F>(io_lo, io_hi, io_log_lo, row_start + i);   // offset^-1 * g^-(global row)
-    T scale[N];
-    scale[0] = cst.inv_n;
-#pragma unroll
-    for (int k = 1; k < N; k++) scale[k] = F::mul(scale[k - 1], io);
     T al[D], acc[D];
 #pragma unroll
-    for (int d = 0; d < D; d++) { al[d] = d_alpha ? d_alpha[d] : cst.alpha[d]; acc[d] = F::zero(); }   // alpha from the host, or where the device coin drew it
-#pragma unroll
-    for (int k = N - 1; k >= 0; k--) {
-        T tmp[D];
-        F::template ext_mul<D>(acc, al, tmp);
-        const int src = brev((N - k) & (N - 1), LOG_NF);
-#pragma unroll
-        for (int d = 0; d < D; d++) acc[d] = F::add(tmp[d], F::mul(comp[d][src], scale[k]));
-    }
+    for (int d = 0; d < D; d++) al[d] = d_alpha ? d_alpha[d] : cst.alpha[d];   // alpha from the host, or where the device coin drew it
+    fri_fold_row<F, LOG_NF, D>(comp, io, cst.inv_n, al, w16, acc);
 #pragma unroll
     for (int d = 0; d < D; d++) out[i * D + d] = acc[d];
 }
@@ -166,25 +161,77 @@ int apply_drp(wf_ctx *ctx, uint32_t D, const void *d_transposed, uint32_t log_le
     return WF_ERR_UNSUPPORTED;
 }
 
-// FriProver::build_layers' loop (mod.rs:179-199) with the channel's coin on the device: nothing in here waits for the stream
+// layer k's fold and layer k + 1's transpose + leaf hashes in one launch (fri_rows.hip: f64, BLAKE3 family, rows <= 128 bytes);
+// *done = 0 when the shape has no fused kernel
+template <class HF>
+int fold_commit(wf_ctx *ctx, int hash, uint32_t D, const void *d_transposed, uint32_t log_len, uint32_t log_nf, const void *h_domain_offset,
+                const void *d_alpha, void *d_folded, void *d_transposed_next, void *d_leaves_next, int *done) {
+    typedef typename HF::T T;
+    *done = 0;
+    if constexpr (sizeof(T) != 8) {
+        return WF_OK;
+    } else {
+        if (HF::Dev::ID != WF_FIELD_F64) return WF_OK;
+        const uint32_t log_rc = log_len - log_nf;
+        if (log_rc < log_nf) return WF_OK;
+        T off;
+        WF_TRY(wf_load_offset<HF>(h_domain_offset, &off));
+        SeriesTable io;
+        const T g_inv = HF::invmod(HF::root_of_unity(log_len));
+        WF_TRY(wf_get_series_table<HF>(ctx, g_inv, HF::invmod(off), log_rc, &io));
+        void *w256, *w16;
+        WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16));
+        const T inv_n = HF::to_internal(HF::invmod(HF::from_u64(1ull << log_nf)));
+        const T g_step = HF::to_internal(HF::powmod(g_inv, 1ull << (log_rc - log_nf)));      // rows i2 + j * rc2: g^-(rc2) per step of j
+        return wf_fri_fold_commit(ctx, hash, WF_FIELD_F64, D, log_nf, d_transposed, 1ull << log_rc, io.d_lo, io.d_hi, io.log_lo, w16, (uint64_t)inv_n, d_alpha,
+                                  (uint64_t)g_step, d_folded, d_transposed_next, d_leaves_next, done);
+    }
+}
+
+// FriProver::build_layers' loop (mod.rs:179-199) with the channel's coin on the device: nothing in here waits for the stream.
+//   commit layer 0;  for every layer k: reseed with its root, draw alpha_k, fold — together with the first half of layer k + 1's
+//   commit where a fused kernel exists — and build layer k + 1's tree
 template <class HF>
 int build_layers(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_t log_len, uint32_t folding, uint32_t num_layers,
                  const void *h_domain_offset, void *d_coin, void *const *d_transposed, void *const *d_leaves, void *const *d_nodes,
-                 void *const *d_folded, void *d_roots, void *d_alphas) {
+                 void *const *d_folded, void *d_roots, void *d_alphas, uint32_t blowup, void *d_remainder) {
     typedef typename HF::T T;
     uint32_t log_nf;
     WF_TRY(check_args(HF::Dev::MAX_EXT, D, log_len, folding, &log_nf));
     if ((uint64_t)num_layers * log_nf > log_len) return WF_ERR_INVALID_ARG;
-    const void *ev = d_evals;
-    for (uint32_t k = 0; k < num_layers; k++) {
+    if (d_remainder && (blowup == 0 || (blowup & (blowup - 1)) || ((uint64_t)blowup >> (log_len - num_layers * log_nf)) > 1)) return WF_ERR_INVALID_ARG;
+    for (uint32_t k = 0; k < num_layers; k++)
         if (!d_transposed[k] || !d_leaves[k] || !d_nodes[k] || !d_folded[k]) return WF_ERR_INVALID_ARG;
-        WF_TRY(layer_commit<HF>(ctx, hash, D, ev, log_len, folding, d_transposed[k], d_leaves[k], d_nodes[k], nullptr));
+    WF_TRY(layer_commit<HF>(ctx, hash, D, d_evals, log_len, folding, d_transposed[0], d_leaves[0], d_nodes[0], nullptr));
+    for (uint32_t k = 0; k < num_layers; k++) {
         void *alpha = (uint8_t *)d_alphas + (size_t)k * D * sizeof(T);
         // channel.commit_fri_layer(root) and channel.draw_fri_alpha(), one launch
         WF_TRY(wf_coin_reseed_draw(ctx, hash, HF::Dev::ID, D, d_coin, (const uint8_t *)d_nodes[k] + 32, (uint8_t *)d_roots + (size_t)k * 32, alpha));
-        WF_TRY(apply_drp<HF>(ctx, D, d_transposed[k], log_len, folding, 0, 1ull << (log_len - log_nf), h_domain_offset, nullptr, alpha, d_folded[k]));
-        ev = d_folded[k];
+        int fused = 0;
+        if (k + 1 < num_layers)
+            WF_TRY(fold_commit<HF>(ctx, hash, D, d_transposed[k], log_len, log_nf, h_domain_offset, alpha, d_folded[k], d_transposed[k + 1], d_leaves[k + 1],
+                                   &fused));
+        if (fused) {
+            WF_TRY(wf_merkle_build(ctx, hash, d_leaves[k + 1], 1ull << (log_len - 2 * log_nf), d_nodes[k + 1]));
+        } else {
+            WF_TRY(apply_drp<HF>(ctx, D, d_transposed[k], log_len, folding, 0, 1ull << (log_len - log_nf), h_domain_offset, nullptr, alpha, d_folded[k]));
+            if (k + 1 < num_layers)
+                WF_TRY(layer_commit<HF>(ctx, hash, D, d_folded[k], log_len - log_nf, folding, d_transposed[k + 1], d_leaves[k + 1], d_nodes[k + 1], nullptr));
+        }
         log_len -= log_nf;
+    }
+    if (d_remainder) {
+        // set_remainder (mod.rs:230-239) on the stream as well: interpolate the last evaluations over the coset (in place), keep
+        // len / blowup coefficients in reverse order, hash them, and the commitment goes into the coin like a layer root
+        void *ev = num_layers ? d_folded[num_layers - 1] : const_cast<void *>(d_evals);
+        if (log_len > 0) WF_TRY(wf_fft_interpolate_poly_with_offset(ctx, HF::Dev::ID, D, ev, log_len, h_domain_offset));
+        const uint32_t size = (uint32_t)((1ull << log_len) / blowup), ew = D;
+        if (size == 0) return WF_ERR_INVALID_ARG;
+        hipLaunchKernelGGL(reverse_prefix_kernel<T>, dim3((size * ew + 255) / 256), dim3(256), 0, ctx->stream, (const T *)ev, (T *)d_remainder, size, ew);
+        WF_HIP(hipGetLastError());
+        void *com = (uint8_t *)d_roots + (size_t)num_layers * 32;
+        WF_TRY(wf_hash_elements_batch(ctx, hash, HF::Dev::ID, d_remainder, 1, (uint64_t)size * D, size * D, com));
+        WF_TRY(wf_coin_reseed(ctx, hash, d_coin, com, nullptr));
     }
     return WF_OK;
 }
@@ -194,16 +241,19 @@ int build_layers(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
 extern "C" int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_len,
                                    uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
                                    void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded,
-                                   void *d_roots, void *d_alphas) {
+                                   void *d_roots, void *d_alphas, uint32_t blowup, void *d_remainder) {
     if (!ctx || !d_evals || !h_domain_offset || !d_coin || !d_roots || !d_alphas) return WF_ERR_INVALID_ARG;
-    if (num_layers == 0) return WF_OK;
-    if (!d_transposed || !d_leaves || !d_nodes || !d_folded) return WF_ERR_INVALID_ARG;
+    if (num_layers == 0 && !d_remainder) return WF_OK;
+    if (num_layers && (!d_transposed || !d_leaves || !d_nodes || !d_folded)) return WF_ERR_INVALID_ARG;
+#define WF_BL(HF) return build_layers<HF>(ctx, hash, ext_degree, d_evals, log_len, folding, num_layers, h_domain_offset, d_coin, d_transposed, d_leaves, \
+                                          d_nodes, d_folded, d_roots, d_alphas, blowup, d_remainder)
     switch (field) {
-        case WF_FIELD_F64: return build_layers<HostF64>(ctx, hash, ext_degree, d_evals, log_len, folding, num_layers, h_domain_offset, d_coin, d_transposed, d_leaves, d_nodes, d_folded, d_roots, d_alphas);
-        case WF_FIELD_F128: return build_layers<HostF128>(ctx, hash, ext_degree, d_evals, log_len, folding, num_layers, h_domain_offset, d_coin, d_transposed, d_leaves, d_nodes, d_folded, d_roots, d_alphas);
-        case WF_FIELD_F62: return build_layers<HostF62>(ctx, hash, ext_degree, d_evals, log_len, folding, num_layers, h_domain_offset, d_coin, d_transposed, d_leaves, d_nodes, d_folded, d_roots, d_alphas);
+        case WF_FIELD_F64: WF_BL(HostF64);
+        case WF_FIELD_F128: WF_BL(HostF128);
+        case WF_FIELD_F62: WF_BL(HostF62);
         default: return WF_ERR_UNSUPPORTED;
     }
+#undef WF_BL
 }
 
 extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals,

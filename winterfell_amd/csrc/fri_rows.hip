@@ -1,5 +1,7 @@
 // FRI layer commit, first half: transpose_slice + hash of every row in one pass (fri/src/prover/mod.rs:321-336).
 #include "hashers.cuh"
+#include "fri_fold.cuh"
+#include "tables.cuh"
 
 namespace {
 
@@ -134,6 +136,92 @@ int launch_fri_rows(wf_ctx *ctx, int mode, const uint64_t *ev, uint64_t rc, uint
     return WF_OK;
 }
 
+// apply_drp of layer k fused with the first half of layer k + 1's commit (f64, BLAKE3 family, rows of <= 128 bytes): lane i2 owns
+// row i2 of the NEXT layer, i.e. the folded values of the current layer's rows i2 + j * rc2 (j < N).  It reads those N rows
+// (64-byte runs, contiguous across the lanes), folds each at alpha (fri_fold_row), writes the N folded values to their places in the
+// natural-order vector (the layer's evaluations: the API hands them out, the remainder needs the last one), hashes the new row out of
+// registers and writes the transposed copy through the per-wavefront LDS stage of fri_rows_direct_kernel.  Against fold, then
+// transpose + hash: one launch less per layer, and the folded vector is not read back.
+template <class H, int LOG_NF, int D>
+__global__ __launch_bounds__(256) void fri_fold_commit_kernel(const uint64_t *t, uint64_t rc, const uint64_t *io_lo, const uint64_t *io_hi, uint32_t io_log_lo,
+                                                              const uint64_t *w16, uint64_t inv_n, const uint64_t *d_alpha, uint64_t g_step,
+                                                              uint64_t *folded, uint64_t *tr_next, void *leaves_next) {
+    typedef F64 F;
+    constexpr int N = 1 << LOG_NF, RW = N * D, CP = RW / 2;
+    constexpr bool POW2 = (CP & (CP - 1)) == 0;
+    constexpr int SPREAD = POW2 && CP < 16 ? 16 / CP : 1;
+    __shared__ uint4 stage[4][64 * (CP > 0 ? CP : 1)];
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint64_t rc2 = rc >> LOG_NF;
+    const uint64_t wave_row0 = (uint64_t)blockIdx.x * 256 + wave * 64;
+    const uint64_t i2 = wave_row0 + lane;
+    auto swz = [&](uint32_t row) -> uint32_t { return POW2 ? ((row / SPREAD) & (CP - 1)) : 0u; };
+    uint64_t w[RW];
+#pragma unroll
+    for (int i = 0; i < RW; i++) w[i] = 0;
+    if (i2 < rc2) {
+        uint64_t al[D];
+#pragma unroll
+        for (int d = 0; d < D; d++) al[d] = d_alpha[d];
+        uint64_t io = series_at<F>(io_lo, io_hi, io_log_lo, i2);          // offset^-1 * g^-i2; row i2 + j * rc2 has io * g_step^j
+#pragma unroll
+        for (int j = 0; j < N; j++) {
+            const uint64_t r = i2 + (uint64_t)j * rc2;
+            uint64_t comp[D][N];
+            const uint64_t *row = t + r * RW;
+#pragma unroll
+            for (int e = 0; e < N; e++)
+#pragma unroll
+                for (int d = 0; d < D; d++) comp[d][e] = row[e * D + d];
+            uint64_t acc[D];
+            fri_fold_row<F, LOG_NF, D>(comp, io, inv_n, al, w16, acc);
+#pragma unroll
+            for (int d = 0; d < D; d++) {
+                w[j * D + d] = acc[d];
+                folded[r * D + d] = acc[d];
+            }
+            if (j + 1 < N) io = F::mul(io, g_step);
+        }
+        uint32_t dg[8];
+        H::template hash_elems<MODE_F64_CANON, false>(w, RW, dg);
+        store_digest(leaves_next, i2, dg);
+    }
+    if constexpr (CP == 1) {
+        if (i2 < rc2) reinterpret_cast<uint4 *>(tr_next)[i2] = make_uint4((uint32_t)w[0], (uint32_t)(w[0] >> 32), (uint32_t)w[1], (uint32_t)(w[1] >> 32));
+    } else {
+        uint4 *st = stage[wave];
+#pragma unroll
+        for (int c = 0; c < CP; c++)
+            st[lane * CP + (c ^ swz(lane))] = make_uint4((uint32_t)w[2 * c], (uint32_t)(w[2 * c] >> 32), (uint32_t)w[2 * c + 1], (uint32_t)(w[2 * c + 1] >> 32));
+        __syncthreads();
+        if (wave_row0 >= rc2) return;
+        const uint32_t nv = rc2 - wave_row0 < 64 ? (uint32_t)(rc2 - wave_row0) : 64u;
+        uint4 *out = reinterpret_cast<uint4 *>(tr_next + wave_row0 * RW);
+#pragma unroll
+        for (int i = 0; i < CP; i++) {
+            const uint32_t L = i * 64 + lane, rr = L / CP, cc = L % CP;
+            if (rr < nv) out[L] = st[rr * CP + (cc ^ swz(rr))];
+        }
+    }
+}
+
+template <class H>
+bool try_fri_fold_commit(wf_ctx *ctx, uint32_t D, uint32_t log_nf, const uint64_t *t, uint64_t rc, const uint64_t *io_lo, const uint64_t *io_hi,
+                         uint32_t io_log_lo, const uint64_t *w16, uint64_t inv_n, const uint64_t *d_alpha, uint64_t g_step, uint64_t *folded,
+                         uint64_t *tr_next, void *leaves_next) {
+    if constexpr (!H::WAVE_TREE) {
+        return false;
+    } else {
+        const uint64_t rc2 = rc >> log_nf;
+        if (rc2 == 0 || (rc2 + 255) / 256 > 0x7fffffffull) return false;
+        const dim3 grid((uint32_t)((rc2 + 255) / 256));
+#define WF_FC(LN, DD) if (log_nf == LN && D == DD) { hipLaunchKernelGGL((fri_fold_commit_kernel<H, LN, DD>), grid, dim3(256), 0, ctx->stream, t, rc, io_lo, io_hi, io_log_lo, w16, inv_n, d_alpha, g_step, folded, tr_next, leaves_next); return true; }
+        WF_FC(1, 1) WF_FC(1, 2) WF_FC(1, 3) WF_FC(2, 1) WF_FC(2, 2) WF_FC(2, 3) WF_FC(3, 1) WF_FC(3, 2) WF_FC(4, 1)
+#undef WF_FC
+        return false;
+    }
+}
+
 }  // namespace
 
 // used by wf_fri_layer_commit (fri.hip): *done = 0 when the caller should take the unfused path (small Rescue layers, where the
@@ -153,4 +241,26 @@ int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree,
     return with_hasher(hash, [&](auto h) {
         return launch_fri_rows<decltype(h)>(ctx, mode, (const uint64_t *)d_evals, rc, 1u << log_nf, EW, (uint64_t *)d_transposed, d_leaves);
     });
+}
+
+// FriProver::build_layers, layer k's fold + layer k + 1's transpose and leaf hashes in one launch (f64; *done = 0: not this shape,
+// the caller runs the two steps separately).  io_*: the series offset^-1 * g^-i of the CURRENT layer, g_step = g^-(rows of the next
+// layer), all in internal form; d_alpha on the device.
+int wf_fri_fold_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, uint32_t log_nf, const void *d_transposed, uint64_t rc, const void *io_lo,
+                       const void *io_hi, uint32_t io_log_lo, const void *w16, uint64_t inv_n, const void *d_alpha, uint64_t g_step, void *d_folded,
+                       void *d_transposed_next, void *d_leaves_next, int *done) {
+    *done = 0;
+    if (field != WF_FIELD_F64) return WF_OK;
+    bool ok = false;
+    wf_prof_begin(ctx, "fri_fold_commit");
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        ok = try_fri_fold_commit<decltype(h)>(ctx, ext_degree, log_nf, (const uint64_t *)d_transposed, rc, (const uint64_t *)io_lo, (const uint64_t *)io_hi,
+                                              io_log_lo, (const uint64_t *)w16, inv_n, (const uint64_t *)d_alpha, g_step, (uint64_t *)d_folded,
+                                              (uint64_t *)d_transposed_next, d_leaves_next);
+        return (int)WF_OK;
+    }));
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    *done = ok ? 1 : 0;
+    return WF_OK;
 }

@@ -142,6 +142,9 @@ int wf_evaluate_polys_over_fused(wf_ctx *ctx, int field, uint32_t ext_degree, co
                                  int *fused);   // fft_api.hip
 int wf_lde_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_tmp, void *d_lde, uint32_t base_cols,
                           uint32_t log_n, uint32_t log_b, uint32_t log_tm, void *d_leaves, int *done);   // hash_kernels.hip
+int wf_fri_fold_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, uint32_t log_nf, const void *d_transposed, uint64_t rc, const void *io_lo,
+                       const void *io_hi, uint32_t io_log_lo, const void *w16, uint64_t inv_n, const void *d_alpha, uint64_t g_step, void *d_folded,
+                       void *d_transposed_next, void *d_leaves_next, int *done);
 int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
                           void *d_transposed, void *d_leaves, int *done);   // hash_kernels.hip
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field

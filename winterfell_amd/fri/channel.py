@@ -8,13 +8,19 @@ from ..crypto.random import DefaultRandomCoin
 from ..math import fields
 
 
+_EMPTY_SEEDS = {}       # hash_elements(&[]) per (hasher, field): RandomCoin::new(&[]) is the same for every channel
+
+
 class DefaultProverChannel:
     def __init__(self, domain_size, num_queries, hasher, ext_degree=1, field=fields.f64, ctx=None, device_coin=True):
         assert domain_size >= 8, "domain size must be at least 8, but was %d" % domain_size                       # channel.rs:82
         assert domain_size & (domain_size - 1) == 0, "domain size must be a power of two, but was %d" % domain_size
         assert num_queries > 0, "number of queries must be greater than zero"
         self.hasher, self.field, self.D, self.ctx = hasher, field, ext_degree, ctx
-        self.public_coin = DefaultRandomCoin(hasher, field, np.zeros(0, dtype=np.uint64), ctx)                    # RandomCoin::new(&[])
+        key = (hasher.HASH_ID, field.name)
+        if key not in _EMPTY_SEEDS:
+            _EMPTY_SEEDS[key] = DefaultRandomCoin(hasher, field, np.zeros(0, dtype=np.uint64), ctx).seed             # RandomCoin::new(&[])
+        self.public_coin = DefaultRandomCoin.from_seed(hasher, field, _EMPTY_SEEDS[key], ctx)
         self.commitments, self.alphas = [], []
         self.domain_size, self.num_queries = domain_size, num_queries
         self._device_coin = device_coin and hasher.DEVICE_COIN
@@ -40,8 +46,10 @@ class DefaultProverChannel:
     def fri_device_coin(self):
         return self.public_coin.to_device() if self._device_coin else None
 
-    def absorb_fri_layers(self, device_coin, roots, alphas):
+    def absorb_fri_layers(self, device_coin, roots, alphas, remainder_commitment=None):
         for root, alpha in zip(roots, alphas):
             self.commitments.append(np.array(root, copy=True))
             self.alphas.append(np.array(alpha, copy=True))
+        if remainder_commitment is not None:                    # the remainder's commit_fri_layer happened on the device as well
+            self.commitments.append(np.array(remainder_commitment, copy=True))
         self.public_coin.take_back(device_coin)

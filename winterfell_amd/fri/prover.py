@@ -70,9 +70,8 @@ class FriProver:
         off = f.element_words(int(self.options.domain_offset()))
         off_p = off.ctypes.data_as(ctypes.c_void_p)
         coin = channel.fri_device_coin() if hasattr(channel, "fri_device_coin") else None
-        if coin is not None:
-            ev, length = self._build_layers_fused(channel, coin, ev, length, off_p)
-            return self._set_remainder(channel, ev, length)
+        if coin is not None and self.options.num_fri_layers(length) > 0:
+            return self._build_layers_fused(channel, coin, ev, length, off_p)
         for _ in range(self.options.num_fri_layers(length)):
             log_len = length.bit_length() - 1
             rows = length // N
@@ -95,15 +94,14 @@ class FriProver:
         self._set_remainder(channel, ev, length)
 
     def _build_layers_fused(self, channel, coin, ev, length, off_p):
-        """the same loop as one library call against a device-resident coin (wf_fri_build_layers): commit, reseed, draw, fold
-        for every layer are queued back to back; roots, alphas and the coin come back in one read at the end"""
+        """the same loop AND the remainder step as one library call against a device-resident coin (wf_fri_build_layers): commit,
+        reseed, draw, fold for every layer, then interpolate / reverse / hash / reseed for the remainder, are queued back to back;
+        roots, alphas, the remainder and the coin come back in one read at the end"""
         ctx, D, N, f = self.ctx, self.D, self.options.folding_factor, self.options.field
         nl = self.options.num_fri_layers(length)
-        if nl == 0:
-            return ev, length
         log_len = length.bit_length() - 1
         ew = D * f.W * 8                                         # bytes per E element
-        # one allocation for every layer's four arrays, one for what comes back (roots | alphas | the coin)
+        # one allocation for every layer's four arrays, one for what comes back (roots | alphas | remainder | the coin)
         sizes, rows = [], length
         for _ in range(nl):
             rows //= N
@@ -117,18 +115,22 @@ class FriProver:
             nd.append(pool[at + a + b:at + a + b + c].view(r, 32))
             fo.append(pool[at + a + b + c:at + a + b + c + d].view(torch_u64()))
             at += a + b + c + d
-        back = ctx.empty_u8(nl * 32 + nl * ew + 64)
-        roots, alphas, state = back[:nl * 32], back[nl * 32:nl * (32 + ew)], back[nl * (32 + ew):]
+        rem_size = rows // self.options.blowup_factor
+        assert rem_size >= 1
+        o_alpha, o_rem, o_coin = (nl + 1) * 32, (nl + 1) * 32 + nl * ew, (nl + 1) * 32 + nl * ew + rem_size * ew
+        back = ctx.empty_u8(o_coin + 64)
+        roots, alphas, rem, state = back[:o_alpha], back[o_alpha:o_rem], back[o_rem:o_coin], back[o_coin:]
         coin.move_to(state)
         arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
         ctx.call("wf_fri_build_layers", self.hasher.HASH_ID, f.ID, D, ptr(ev), log_len, N, nl, off_p, ptr(coin.state), arr(tr), arr(lv), arr(nd),
-                 arr(fo), ptr(roots), ptr(alphas))
-        host = ctx.to_host(back)                                 # the one wait of the layer loop
-        coin.set_host_image(host[nl * (32 + ew):])
-        channel.absorb_fri_layers(coin, host[:nl * 32].reshape(nl, 32), host[nl * 32:nl * (32 + ew)].view(np.uint64).reshape(nl, D * f.W))
+                 arr(fo), ptr(roots), ptr(alphas), self.options.blowup_factor, ptr(rem))
+        host = ctx.to_host(back)                                 # the one wait of the commit phase
+        coin.set_host_image(host[o_coin:])
+        h_roots = host[:o_alpha].reshape(nl + 1, 32)
+        channel.absorb_fri_layers(coin, h_roots[:nl], host[o_alpha:o_rem].view(np.uint64).reshape(nl, D * f.W), remainder_commitment=h_roots[nl])
         for k in range(nl):
             self.layers.append(FriLayer(MerkleTree(self.hasher, lv[k], nd[k], ctx), tr[k]))
-        return fo[-1], rows
+        self.remainder_poly = np.array(host[o_rem:o_coin].view(np.uint64).reshape(rem_size, D * f.W), copy=True)
 
     def _set_remainder(self, channel, ev, length):
         """mod.rs:230-239: interpolate over the coset, keep len/blowup coefficients in reverse order, commit to them."""

@@ -121,11 +121,13 @@ class ProverChannel:
         """the public coin, handed to the device for the layer loop; None when the hasher does not suit (hash.py DEVICE_COIN)"""
         return self.public_coin.to_device() if self.hasher.DEVICE_COIN else None
 
-    def absorb_fri_layers(self, device_coin, roots, alphas):
+    def absorb_fri_layers(self, device_coin, roots, alphas, remainder_commitment=None):
         """what commit_fri_layer / draw_fri_alpha would have recorded layer by layer, then the coin back on the host"""
         for root, alpha in zip(roots, alphas):
             self.commitments.append(np.array(root, copy=True))
             self.fri_alphas.append(np.array(alpha, copy=True))
+        if remainder_commitment is not None:                    # the remainder's commit_fri_layer happened on the device as well
+            self.commitments.append(np.array(remainder_commitment, copy=True))
         self.public_coin.take_back(device_coin)
 
     # ---- query phase (channel.rs:146-185)
