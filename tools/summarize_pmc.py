@@ -24,22 +24,25 @@ import re
 
 def traffic(last, twtab):
     """(2 x FETCH_SIZE + WRITE_SIZE) bytes per launch of the radix-256 f64 pass kernel with these template flags
-    (ntt_pass<F64, LOG_A, LOG_B, LAST, TWTAB, PF = false>)."""
-    tot = 0.0
+    (ntt_pass<F64, LOG_A, LOG_B, LAST, TWTAB, PF = false>), and how many launches the counter pass saw."""
+    tot, launches = 0.0, 0
     for k, cs in kernels.items():
         m = re.search(r"ntt_pass<F64, 4, 4, (true|false), (true|false), false>", k)
         if m and (m.group(1) == "true") == last and (m.group(2) == "true") == twtab and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             tot = (2 * cs["FETCH_SIZE"]["avg"] + cs["WRITE_SIZE"]["avg"]) * 1024
-    return tot
+            launches = cs["FETCH_SIZE"]["launches"]
+    return tot, launches
 
 
-# a 2^24-point transform = progression pass (first) + table pass (second) + last pass
-p0, p1, l = traffic(False, False), traffic(False, True), traffic(True, False)
-p = p0
+# a 2^24-point transform = two non-last passes (progression twiddles; a table pass only in -DNTT_F64_TW_TABLES builds) + the last
+# pass: the launch counts of the counter run say how many of each there are per transform
+(p0, n0), (p1, n1), (l, nl) = traffic(False, False), traffic(False, True), traffic(True, False)
+per_transform = (p0 * n0 + p1 * n1 + l * nl) / nl if nl else 0.0
 out = {
     "note": "rocprofv3 --pmc, separate passes for FETCH_SIZE / WRITE_SIZE / SQ_*; bench.py --steps 3 --log-n 24; FETCH_SIZE doubled per the gfx950 correction",
     "ntt_2^24_f64": {"ntt_pass_progression_bytes_per_launch": p0, "ntt_pass_table_bytes_per_launch": p1, "ntt_pass_last_bytes_per_launch": l,
-                     "hbm_bytes_per_transform": p0 + p1 + l,
+                     "launches_per_transform": {"progression": n0 / nl if nl else 0, "table": n1 / nl if nl else 0, "last": 1},
+                     "hbm_bytes_per_transform": per_transform,
                      "algorithmic_bytes_per_transform": 268435456},
     "kernels": kernels,
 }
