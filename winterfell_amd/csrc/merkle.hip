@@ -14,9 +14,14 @@ template <class H, int THREADS = 256>
 __global__ __launch_bounds__(THREADS) void merkle_stage_kernel(const void *in, void *nodes, uint64_t count, uint32_t log_ch) {
     __shared__ uint4 bufA[512 * 2];
     __shared__ uint4 bufB[256 * 2];
+    // the launch that finishes a tree (one workgroup) also writes nodes[0] = Digest::default(): bit 31 of log_ch asks for it (a
+    // separate 32-byte fill was one more launch in every tree of an FRI commit phase)
+    const bool zero_node0 = (log_ch >> 31) != 0;
+    log_ch &= 0x7fffffffu;
     const uint32_t ch = 1u << log_ch;
     const uint64_t wg = blockIdx.x;
     const int tid = threadIdx.x;
+    if (zero_node0 && wg == 0 && tid < 2) reinterpret_cast<uint4 *>(nodes)[tid] = make_uint4(0, 0, 0, 0);
     // level 0: from global
     {
         const uint32_t cnt = ch >> 1;
@@ -249,7 +254,8 @@ __global__ __launch_bounds__(256) void merkle_wave_kernel(const void *in, void *
 
 template <class H>
 int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *nodes) {
-    WF_HIP(hipMemsetAsync(nodes, 0, 32, ctx->stream));  // nodes[0] = Digest::default()
+    // nodes[0] = Digest::default(): written by the stage launch that finishes the tree; the single-level hashers keep the fill
+    if (H::STAGE_LEVELS == 1) WF_HIP(hipMemsetAsync(nodes, 0, 32, ctx->stream));
     const uint8_t *in = (const uint8_t *)leaves;
     uint64_t count = num_leaves;
     while (count > 1) {
@@ -316,14 +322,15 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
         const uint64_t wgs = count >> log_ch;
         if (wgs > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
         wf_prof_begin(ctx, H::merkle_name());
+        const uint32_t arg = log_ch | (wgs == 1 ? 0x80000000u : 0u);     // the last launch of the tree writes nodes[0] too
         bool wide = false;
         if constexpr (H::QUAD_MERGE) {
             if (wgs <= 256) {
                 wide = true;
-                hipLaunchKernelGGL((merkle_stage_kernel<H, 1024>), dim3((uint32_t)wgs), dim3(1024), 0, ctx->stream, (const void *)in, nodes, count, log_ch);
+                hipLaunchKernelGGL((merkle_stage_kernel<H, 1024>), dim3((uint32_t)wgs), dim3(1024), 0, ctx->stream, (const void *)in, nodes, count, arg);
             }
         }
-        if (!wide) hipLaunchKernelGGL((merkle_stage_kernel<H, 256>), dim3((uint32_t)wgs), dim3(256), 0, ctx->stream, (const void *)in, nodes, count, log_ch);
+        if (!wide) hipLaunchKernelGGL((merkle_stage_kernel<H, 256>), dim3((uint32_t)wgs), dim3(256), 0, ctx->stream, (const void *)in, nodes, count, arg);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
         count = wgs;
