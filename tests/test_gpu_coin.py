@@ -168,3 +168,43 @@ def test_fused_layer_loop_with_a_rescue_hasher(wf, monkeypatch):
     assert len(ca.commitments) == len(cb.commitments) and all(np.array_equal(x, y) for x, y in zip(ca.commitments, cb.commitments))
     assert all(np.array_equal(x, y) for x, y in zip(ca.alphas, cb.alphas)) and np.array_equal(pa.remainder_poly, pb.remainder_poly)
     assert np.array_equal(ca.public_coin.seed, cb.public_coin.seed)
+
+
+@pytest.mark.parametrize("D,N,log_len", [(2, 4, 14), (1, 2, 10), (3, 8, 13), (1, 16, 12)])
+def test_build_layers_hands_out_every_folded_vector(wf, oracle, D, N, log_len):
+    """the C entry point's d_folded[k] (the next layer's evaluations in natural order, an output of the call even where the
+    fold is fused with the next layer's commit) against the oracle's apply_drp, layer by layer with the alphas the call drew;
+    the remainder against set_remainder"""
+    import ctypes
+    from winterfell_amd._lib import ptr
+    ctx, crypto, fri, fields = wf
+    f, hasher = fields.f64, crypto.Blake3_256
+    n, blowup, rem_deg = 1 << log_len, 8, 7
+    ev = oracle.f64_from_int(rand_field(600 + log_len + N, n * D))
+    opts = fri.FriOptions(blowup, N, rem_deg, field=f)
+    nl = opts.num_fri_layers(n)
+    rows, tr, lv, nd, fo = n, [], [], [], []
+    for _ in range(nl):
+        rows //= N
+        tr.append(ctx.empty_u64(rows, N * D)); lv.append(ctx.empty_u8(rows, 32)); nd.append(ctx.empty_u8(rows, 32)); fo.append(ctx.empty_u64(rows * D))
+    rem_size = rows // blowup
+    roots, alphas, rem = ctx.empty_u8(nl + 1, 32), ctx.empty_u64(nl, D), ctx.empty_u64(rem_size, D)
+    coin = crypto.DefaultRandomCoin(hasher, f, np.zeros(0, dtype=np.uint64), ctx).to_device()
+    coin.draw(1)                                                   # uploads the state
+    off = f.element_words(f.new(7))
+    arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
+    d_ev = ctx.to_device(ev)
+    ctx.call("wf_fri_build_layers", hasher.HASH_ID, f.ID, D, ptr(d_ev), log_len, N, nl, off.ctypes.data_as(ctypes.c_void_p), ptr(coin.state), arr(tr),
+             arr(lv), arr(nd), arr(fo), ptr(roots), ptr(alphas), blowup, ptr(rem))
+    h_alphas = ctx.to_host(alphas)
+    cur = ev.copy()
+    for k in range(nl):
+        t = oracle.transpose_slice(cur, N, D)
+        assert np.array_equal(ctx.to_host(tr[k]).reshape(-1), t), "layer %d evaluations" % k
+        _, nodes = oracle.fri_layer_commit(0, t, N, D)
+        assert np.array_equal(ctx.to_host(nd[k]), nodes) and np.array_equal(ctx.to_host(roots)[k], nodes[1])
+        cur = oracle.apply_drp(t, N, fields.new(7), h_alphas[k], D)
+        if k + 1 < nl:                                             # the last one is interpolated in place by the remainder step
+            assert np.array_equal(ctx.to_host(fo[k]), cur), "folded vector %d" % k
+    o_rem, o_com = oracle.fri_remainder(0, cur, fields.new(7), blowup, D)
+    assert np.array_equal(ctx.to_host(rem).reshape(-1), np.asarray(o_rem).reshape(-1)) and np.array_equal(ctx.to_host(roots)[nl], o_com)
