@@ -322,3 +322,19 @@ def test_follows_torchs_current_stream(wf, oracle):
         assert np.array_equal(got, want) and np.array_equal(rt, a)
     torch.cuda.synchronize()
     assert np.array_equal(ctx.to_host(fft.evaluate_poly(ctx.to_device(a))), want)     # and back on the default stream
+
+
+@pytest.mark.parametrize("plan", ["18:6,6,6", "18:8,5,5", "18:5,8,5", "18:4,7,7", "18:8,8,2", "18:7,7,3,1", "18:3,3,3,3,3,3", "18:1,8,8,1"])
+def test_every_pass_plan_gives_the_same_transform(wf, oracle, plan, monkeypatch):
+    """WF_NTT_PLAN (the measurement hook of tools/time_batch_ntt.py) splits a 2^18-point transform into passes of any radix
+    2^1 .. 2^8 in any position (first / middle / last use different kernels): forward, inverse, coset evaluation and a batch of
+    vectors must not depend on the split"""
+    ctx, fft, fields = wf[0], wf[1], wf[2]
+    n = 1 << 18
+    p = oracle.f64_from_int(rand_field(321, n))
+    monkeypatch.setenv("WF_NTT_PLAN", plan)
+    assert np.array_equal(fft.evaluate_poly(p.copy()), oracle.evaluate_poly(p, par=True))
+    assert np.array_equal(fft.interpolate_poly(p.copy()), oracle.interpolate_poly(p, par=True))
+    vecs = oracle.f64_from_int(rand_field(322, 4 * n)).reshape(4, n)
+    want = np.stack([oracle.evaluate_poly(vecs[k], par=True) for k in range(4)])
+    assert np.array_equal(np.asarray(fft.evaluate_poly(vecs.copy(), batch=4)).reshape(4, n), want)
