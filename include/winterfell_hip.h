@@ -333,6 +333,11 @@ int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, c
 int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                      uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded);
 
+/* wf_fri_apply_drp_rows with alpha in device memory (where wf_coin_draw / wf_coin_reseed_draw put it). */
+int wf_fri_apply_drp_rows_dev(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
+                              uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
+                              const void *d_alpha, void *d_folded);
+
 /* FriProver::build_layers (fri/src/prover/mod.rs:179-239) against a device-resident coin: for each of the num_layers layers
  * build_layer = commit (as wf_fri_layer_commit), channel.commit_fri_layer(root) = coin.reseed(root),
  * alpha = channel.draw_fri_alpha() = coin.draw::<E>(), apply_drp (as wf_fri_apply_drp) — queued back to back on the
@@ -394,6 +399,24 @@ int wf_comm_all_to_all(wf_comm *comm, const void *d_send, void *d_recv, uint64_t
 int wf_comm_sharded_commit(wf_comm *comm, int hash, int field, uint32_t ext_degree, void *d_trace_shard, uint32_t shard_cols,
                            uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, int skip_interpolate,
                            void *d_lde_shard, void *d_leaves, void *d_nodes, void *d_top, void *h_root);
+
+/* FriProver::build_layers with the layers sharded by contiguous row ranges, this rank's part (call it on every rank; DESIGN.md
+ * section 6): rank r holds piece r — the contiguous 2^log_len / G evaluations [r len/G, (r+1) len/G) — of the first layer.
+ * For each of the num_layers layers (the caller picks how many stay sharded: rows per rank >= 2 and a multiple of G):
+ *   1. re-stride: the rank needs rows [r rc/G, (r+1) rc/G) of the transposed layer, i.e. chunk (j, r) of every strided run j —
+ *      one all-to-all of equal blocks when G divides the folding factor, one all-gather of the layer otherwise;
+ *   2. the rank's rows, their leaves and the subtree over them (as wf_fri_layer_commit);  3. all-gather of the G sub-roots,
+ *      top tree on every rank;  4. coin.reseed(root), alpha = coin.draw() on every rank's identical device coin;
+ *   5. fold the local rows with their GLOBAL row index (as wf_fri_apply_drp_rows): the rank's piece of the next layer.
+ * Outputs per layer k (host arrays of device pointers): d_rows[k] rows_local x folding elements, d_leaves[k] / d_nodes[k]
+ * rows_local x 32 bytes (subtree, heap order), d_top[k] G x 32 bytes (heap order, [1] = the layer root; G = 1: the root at
+ * [0]), d_folded[k] rows_local elements; d_roots num_layers x 32, d_alphas num_layers elements — identical on every rank.
+ * Node for node FriProver::build_layers on one device (tests/test_gpu_comm.py).  The caller gathers the last pieces
+ * (wf_comm_all_gather) and finishes the small layers and the remainder unsharded (wf_fri_build_layers on every rank). */
+int wf_comm_sharded_fri_layers(wf_comm *comm, int hash, int field, uint32_t ext_degree, const void *d_piece, uint32_t log_len,
+                               uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
+                               void *const *d_rows, void *const *d_leaves, void *const *d_nodes, void *const *d_top,
+                               void *const *d_folded, void *d_roots, void *d_alphas);
 
 #ifdef __cplusplus
 }

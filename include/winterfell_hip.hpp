@@ -450,6 +450,44 @@ public:
         return r;
     }
 
+    // FriProver::build_layers with the layers sharded by contiguous row ranges (wf_comm_sharded_fri_layers): this rank's piece of
+    // the evaluations in, per layer this rank's rows / leaves / subtree, the top tree, its piece of the next layer; roots and alphas
+    // (device) are identical on every rank.  `coin`: this rank's copy of the device coin (64 bytes, WF_COIN_BYTES).
+    struct ShardedFriLayer {
+        DeviceBuffer rows, leaves, nodes, top, folded;
+    };
+    struct ShardedFri {
+        std::vector<ShardedFriLayer> layers;
+        DeviceBuffer roots, alphas;
+    };
+    ShardedFri sharded_fri_layers(Hash h, Field f, uint32_t ext_degree, const DeviceBuffer &piece, uint64_t length, uint32_t folding, uint32_t num_layers,
+                                  const uint64_t *domain_offset, void *d_coin) {
+        Context &ctx = *ctx_;
+        const size_t eb = (size_t)ext_degree * words(f) * 8;
+        ShardedFri out;
+        std::vector<void *> p_rows, p_leaves, p_nodes, p_top, p_folded;
+        uint64_t len = length;
+        for (uint32_t k = 0; k < num_layers; k++) {
+            const uint64_t rl = len / folding / (uint64_t)size();
+            out.layers.push_back(ShardedFriLayer{DeviceBuffer(ctx, rl * folding * eb), DeviceBuffer(ctx, rl * 32), DeviceBuffer(ctx, rl * 32),
+                                                 DeviceBuffer(ctx, (size_t)size() * 32), DeviceBuffer(ctx, rl * eb)});
+            ShardedFriLayer &l = out.layers.back();
+            p_rows.push_back(l.rows.data());
+            p_leaves.push_back(l.leaves.data());
+            p_nodes.push_back(l.nodes.data());
+            p_top.push_back(l.top.data());
+            p_folded.push_back(l.folded.data());
+            len /= folding;
+        }
+        out.roots = DeviceBuffer(ctx, (size_t)num_layers * 32);
+        out.alphas = DeviceBuffer(ctx, (size_t)num_layers * eb);
+        check(wf_comm_sharded_fri_layers(c_, (int)h, (int)f, ext_degree, piece.data(), log2_exact(length, "evaluations"), folding, num_layers, domain_offset,
+                                         d_coin, p_rows.data(), p_leaves.data(), p_nodes.data(), p_top.data(), p_folded.data(), out.roots.data(),
+                                         out.alphas.data()),
+              "wf_comm_sharded_fri_layers");
+        return out;
+    }
+
 private:
     Comm(wf_comm *c, Context *ctx) : c_(c), ctx_(ctx) {}
     wf_comm *c_;

@@ -179,3 +179,79 @@ def test_rccl_transport_with_one_rank(wf, oracle):
         assert np.array_equal(res["leaves"], o_leaves) and np.array_equal(res["nodes"], o_nodes) and np.array_equal(res["root"], o_nodes[1])
     finally:
         ctx.lib.wf_comm_destroy(cm)
+
+
+@pytest.mark.parametrize("G,N,D,log_len,layers", [(2, 4, 2, 12, 3), (4, 4, 1, 12, 2), (8, 4, 2, 13, 2), (2, 2, 3, 10, 4), (4, 16, 1, 14, 2), (1, 4, 2, 10, 2)])
+def test_sharded_fri_layers_over_loopback(wf, oracle, G, N, D, log_len, layers):
+    """wf_comm_sharded_fri_layers rank for rank (loopback transport, one thread per rank, every rank its own context and its own
+    copy of the device coin) against the single-device commit phase of the oracle: each rank's rows, leaves, subtree, the top
+    tree, every root and alpha, each rank's piece of every folded vector.  G = 8 with folding 4 takes the all-gather re-stride,
+    the others the all-to-all."""
+    ctx, crypto, prover, fields = wf
+    import torch
+    f, hasher, lib = fields.f64, crypto.Blake3_256, ctx.lib
+    n = 1 << log_len
+    ev = oracle.f64_from_int(rand_field(7000 + G * 16 + N, n * D))
+    handles, comms = _make_loopback(ctx, G)
+    per = n // G
+    bufs = []
+    image = np.zeros(64, dtype=np.uint8)
+    image[:32] = crypto.DefaultRandomCoin(hasher, f, np.zeros(0, dtype=np.uint64), ctx).seed
+    for r in range(G):
+        b = dict(piece=ctx.to_device(ev[r * per * D:(r + 1) * per * D]), coin=ctx.to_device(image), rows=[], leaves=[], nodes=[], top=[], folded=[],
+                 roots=ctx.empty_u8(layers, 32), alphas=ctx.empty_u64(layers, D))
+        length = n
+        for _ in range(layers):
+            rl = length // N // G
+            b["rows"].append(ctx.empty_u64(rl, N * D)); b["leaves"].append(ctx.empty_u8(rl, 32)); b["nodes"].append(ctx.empty_u8(rl, 32))
+            b["top"].append(ctx.empty_u8(G, 32)); b["folded"].append(ctx.empty_u64(rl * D))
+            length //= N
+        bufs.append(b)
+    torch.cuda.synchronize()
+    off = f.element_words(f.new(7))
+    errs = []
+
+    def run(r):
+        try:
+            b = bufs[r]
+            arr = lambda ts: (ctypes.c_void_p * layers)(*[t.data_ptr() for t in ts])
+            st = lib.wf_comm_sharded_fri_layers(comms[r], hasher.HASH_ID, f.ID, D, _vp(b["piece"]), log_len, N, layers, off.ctypes.data_as(ctypes.c_void_p),
+                                                _vp(b["coin"]), arr(b["rows"]), arr(b["leaves"]), arr(b["nodes"]), arr(b["top"]), arr(b["folded"]),
+                                                _vp(b["roots"]), _vp(b["alphas"]))
+            assert st == 0, "wf_comm_sharded_fri_layers -> %d" % st
+            assert lib.wf_ctx_sync(handles[r]) == 0
+        except BaseException as e:        # noqa: BLE001
+            errs.append(e)
+    try:
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+        [t.start() for t in ts]
+        [t.join(timeout=300) for t in ts]
+        assert not errs, errs
+    finally:
+        _teardown(ctx, handles, comms)
+    # the single-device commit phase
+    chan = oracle.ProverChannel(0, D)
+    cur, length = ev.copy(), n
+    for k in range(layers):
+        tr = oracle.transpose_slice(cur, N, D).reshape(length // N, N * D)
+        o_leaves, o_nodes = oracle.fri_layer_commit(0, tr.reshape(-1), N, D)
+        chan.commit_fri_layer(o_nodes[1])
+        alpha = chan.draw_fri_alpha()
+        nxt = oracle.apply_drp(tr.reshape(-1), N, fields.new(7), alpha, D).reshape(length // N, D)
+        rl = length // N // G
+        for r in range(G):
+            b = bufs[r]
+            assert np.array_equal(ctx.to_host(b["rows"][k]), tr[r * rl:(r + 1) * rl]), "rows of rank %d, layer %d" % (r, k)
+            assert np.array_equal(ctx.to_host(b["leaves"][k]), o_leaves[r * rl:(r + 1) * rl])
+            got_nodes = ctx.to_host(b["nodes"][k])
+            for j in range(1, rl):
+                depth = j.bit_length() - 1
+                assert np.array_equal(got_nodes[j], o_nodes[((G + r) << depth) + (j - (1 << depth))]), (r, k, j)
+            top = ctx.to_host(b["top"][k])
+            if G > 1:
+                assert np.array_equal(top[1:], o_nodes[1:G]), "top tree on rank %d, layer %d" % (r, k)
+            else:
+                assert np.array_equal(top[0], o_nodes[1])
+            assert np.array_equal(ctx.to_host(b["roots"])[k], o_nodes[1]) and np.array_equal(ctx.to_host(b["alphas"])[k], alpha)
+            assert np.array_equal(ctx.to_host(b["folded"][k]).reshape(rl, D), nxt[r * rl:(r + 1) * rl]), "folded piece of rank %d, layer %d" % (r, k)
+        cur, length = nxt.reshape(-1), length // N

@@ -79,6 +79,8 @@ _PROTOS = {
     "wf_comm_all_gather": [_vp, _vp, _vp, _u64],
     "wf_comm_all_to_all": [_vp, _vp, _vp, _u64],
     "wf_comm_sharded_commit": [_vp, _int, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _int, _vp, _vp, _vp, _vp, _vp],
+    "wf_comm_sharded_fri_layers": [_vp, _int, _int, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "wf_fri_apply_drp_rows_dev": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
 }
 
 _lib = None

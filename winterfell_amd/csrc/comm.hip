@@ -266,3 +266,98 @@ extern "C" int wf_comm_sharded_commit(wf_comm *cm, int hash, int field, uint32_t
     if (h_root) WF_TRY(wf_memcpy_d2h(ctx, h_root, (const uint8_t *)d_top + 32, 32));
     return WF_OK;
 }
+
+namespace {
+// piece chunks [jj][g] -> send blocks [g][jj] (16-byte units): what rank g needs from this rank, in the order it will read it
+__global__ __launch_bounds__(256) void fri_pack_chunks_kernel(const uint4 *piece, uint4 *send, uint64_t chunk_u4, uint32_t G, uint32_t per_dest) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t total = chunk_u4 * G * per_dest;
+    if (i >= total) return;
+    const uint64_t c = i / chunk_u4, w = i - c * chunk_u4;          // c = destination-major chunk index g * per_dest + jj
+    const uint32_t g = (uint32_t)(c / per_dest), jj = (uint32_t)(c % per_dest);
+    send[i] = piece[((uint64_t)jj * G + g) * chunk_u4 + w];
+}
+// from the whole layer: chunk (j, rank) of every strided run j -> [j][rows_local]
+__global__ __launch_bounds__(256) void fri_cut_chunks_kernel(const uint4 *full, uint4 *out, uint64_t chunk_u4, uint32_t G, uint32_t rank, uint32_t N) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= chunk_u4 * N) return;
+    const uint64_t j = i / chunk_u4, w = i - j * chunk_u4;
+    out[i] = full[(j * G + rank) * chunk_u4 + w];
+}
+}  // namespace
+
+extern "C" int wf_comm_sharded_fri_layers(wf_comm *cm, int hash, int field, uint32_t ext_degree, const void *d_piece, uint32_t log_len,
+                                          uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
+                                          void *const *d_rows, void *const *d_leaves, void *const *d_nodes, void *const *d_top,
+                                          void *const *d_folded, void *d_roots, void *d_alphas) {
+    if (!cm || !d_piece || !h_domain_offset || !d_coin || !d_roots || !d_alphas || ext_degree == 0) return WF_ERR_INVALID_ARG;
+    if (num_layers == 0) return WF_OK;
+    if (!d_rows || !d_leaves || !d_nodes || !d_top || !d_folded) return WF_ERR_INVALID_ARG;
+    if (folding != 2 && folding != 4 && folding != 8 && folding != 16) return WF_ERR_UNSUPPORTED;
+    if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
+    wf_ctx *ctx = cm->ctx;
+    const uint32_t G = (uint32_t)cm->world, r = (uint32_t)cm->rank, N = folding;
+    if (G & (G - 1)) return WF_ERR_NOT_POWER_OF_TWO;
+    uint32_t log_nf = 0, log_g = 0;
+    while ((1u << log_nf) < N) log_nf++;
+    while ((1u << log_g) < G) log_g++;
+    const size_t eb = (size_t)ext_degree * (field == WF_FIELD_F128 ? 16 : 8);       // bytes per element of E
+    WF_HIP(hipSetDevice(ctx->device));
+    const void *piece = d_piece;
+    for (uint32_t k = 0; k < num_layers; k++) {
+        if (!d_rows[k] || !d_leaves[k] || !d_nodes[k] || !d_top[k] || !d_folded[k]) return WF_ERR_INVALID_ARG;
+        if (log_len < log_nf + log_g + 1) return WF_ERR_INVALID_ARG;                   // at least two rows per rank (a subtree)
+        const uint64_t len = 1ull << log_len, rows_local = len >> (log_nf + log_g);    // = elements per chunk
+        const size_t chunk_bytes = (size_t)rows_local * eb;
+        if (chunk_bytes % 16) return WF_ERR_INVALID_ARG;
+        const uint64_t chunk_u4 = chunk_bytes / 16;
+        // 1. the rank's chunk-major buffer [N][rows_local]: element (j, i) = e[r rows_local + i + j rc]
+        void *cmaj = nullptr, *tmp = nullptr;
+        if (G == 1) {
+            cmaj = const_cast<void *>(piece);
+        } else if (N % G == 0) {
+            const uint32_t per_dest = N / G;                                           // chunks this rank sends to every rank
+            WF_TRY(wf_malloc(ctx, chunk_bytes * N, &tmp));
+            WF_TRY(wf_malloc(ctx, chunk_bytes * N, &cmaj));
+            const uint64_t total = chunk_u4 * N;
+            hipLaunchKernelGGL(fri_pack_chunks_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)piece, (uint4 *)tmp,
+                               chunk_u4, G, per_dest);
+            WF_HIP(hipGetLastError());
+            WF_TRY(wf_comm_all_to_all(cm, tmp, cmaj, chunk_bytes * per_dest));         // source rank h sends chunks j = h per_dest .. in order
+        } else {
+            WF_TRY(wf_malloc(ctx, chunk_bytes * N * G, &tmp));                         // the whole layer
+            WF_TRY(wf_malloc(ctx, chunk_bytes * N, &cmaj));
+            WF_TRY(wf_comm_all_gather(cm, piece, tmp, chunk_bytes * N));
+            const uint64_t total = chunk_u4 * N;
+            hipLaunchKernelGGL(fri_cut_chunks_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream, (const uint4 *)tmp, (uint4 *)cmaj,
+                               chunk_u4, G, r, N);
+            WF_HIP(hipGetLastError());
+        }
+        // 2. rows, leaves, subtree: the chunk-major buffer is a "layer" of N * rows_local points for the commit
+        WF_TRY(wf_fri_layer_commit(ctx, hash, field, ext_degree, cmaj, log_len - log_g, N, d_rows[k], d_leaves[k], d_nodes[k], nullptr));
+        if (tmp) WF_TRY(wf_free(ctx, tmp));
+        if (G > 1) WF_TRY(wf_free(ctx, cmaj));
+        // 3. sub-roots -> top tree (identical on every rank)
+        const uint8_t *root;
+        if (G == 1) {
+            WF_HIP(hipMemcpyAsync(d_top[k], (const uint8_t *)d_nodes[k] + 32, 32, hipMemcpyDeviceToDevice, ctx->stream));
+            root = (const uint8_t *)d_top[k];
+        } else {
+            void *subs;
+            WF_TRY(wf_malloc(ctx, (size_t)G * 32, &subs));
+            WF_TRY(wf_comm_all_gather(cm, (const uint8_t *)d_nodes[k] + 32, subs, 32));
+            WF_TRY(wf_merkle_build(ctx, hash, subs, G, d_top[k]));
+            WF_TRY(wf_free(ctx, subs));
+            root = (const uint8_t *)d_top[k] + 32;
+        }
+        // 4. channel.commit_fri_layer(root); alpha = channel.draw_fri_alpha() — on this rank's copy of the coin
+        void *alpha = (uint8_t *)d_alphas + (size_t)k * eb;
+        WF_TRY(wf_coin_reseed_draw(ctx, hash, field, ext_degree, d_coin, root, (uint8_t *)d_roots + (size_t)k * 32, alpha));
+        // 5. fold the local rows; x_i uses the global row index
+        WF_TRY(wf_fri_apply_drp_rows_dev(ctx, field, ext_degree, d_rows[k], log_len, N, (uint64_t)r * rows_local, rows_local, h_domain_offset, alpha,
+                                         d_folded[k]));
+        piece = d_folded[k];
+        log_len -= log_nf;
+    }
+    return WF_OK;
+}

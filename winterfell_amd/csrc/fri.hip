@@ -280,6 +280,19 @@ extern "C" int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree
     }
 }
 
+// the same with alpha where the device coin drew it (wf_coin_draw / wf_coin_reseed_draw): nothing crosses to the host
+extern "C" int wf_fri_apply_drp_rows_dev(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
+                                         uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
+                                         const void *d_alpha, void *d_folded) {
+    if (!ctx || !d_transposed_rows || !h_domain_offset || !d_alpha || !d_folded) return WF_ERR_INVALID_ARG;
+    switch (field) {
+        case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, nullptr, d_alpha, d_folded);
+        case WF_FIELD_F128: return apply_drp<HostF128>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, nullptr, d_alpha, d_folded);
+        case WF_FIELD_F62: return apply_drp<HostF62>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, nullptr, d_alpha, d_folded);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+}
+
 extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                                 uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
     uint32_t log_nf = 0;
