@@ -255,3 +255,65 @@ def test_sharded_fri_layers_over_loopback(wf, oracle, G, N, D, log_len, layers):
             assert np.array_equal(ctx.to_host(b["roots"])[k], o_nodes[1]) and np.array_equal(ctx.to_host(b["alphas"])[k], alpha)
             assert np.array_equal(ctx.to_host(b["folded"][k]).reshape(rl, D), nxt[r * rl:(r + 1) * rl]), "folded piece of rank %d, layer %d" % (r, k)
         cur, length = nxt.reshape(-1), length // N
+
+
+@pytest.mark.parametrize("G,min_rows,log_len", [(2, 2, 14), (4, 64, 14), (4, 2, 12), (8, 16, 15)])
+def test_whole_commit_phase_over_a_communicator(wf, G, min_rows, log_len):
+    """parallel.comm_sharded_fri_build_layers — sharded layers (wf_comm_sharded_fri_layers), gather, unsharded tail and remainder
+    (wf_fri_build_layers) — on G loopback ranks against the single-device FriProver: the whole transcript (every layer root, the
+    remainder commitment, every alpha), the remainder polynomial and the coin afterwards, on every rank."""
+    ctx, crypto, prover, fields = wf
+    import torch
+    from winterfell_amd import fri, parallel
+    from winterfell_amd._lib import Context
+    f, hasher, lib, D, N = fields.f64, crypto.Blake3_256, ctx.lib, 2, 4
+    n = 1 << log_len
+    rng = np.random.default_rng(31 + G)
+    ev = f.from_ints([int(v) % f.M for v in rng.integers(0, 1 << 63, n * D, dtype=np.uint64)])
+    opts = fri.FriOptions(8, N, 7, field=f)
+    # single device
+    chan = fri.DefaultProverChannel(n, 8, hasher, ext_degree=D, field=f, ctx=ctx)
+    single = fri.FriProver(opts, hasher, ext_degree=D, ctx=ctx)
+    single.build_layers(chan, ev.copy())
+    # G ranks
+    rank_ctx = [Context(ctx.device.index or 0) for _ in range(G)]
+    arr = (ctypes.c_void_p * G)(*[c.handle.value for c in rank_ctx])
+    comms = (ctypes.c_void_p * G)()
+    assert lib.wf_comm_init_loopback(arr, G, comms) == 0
+    comms = [ctypes.c_void_p(c) for c in comms]
+    image = np.zeros(64, dtype=np.uint8)
+    image[:32] = crypto.DefaultRandomCoin(hasher, f, np.zeros(0, dtype=np.uint64), ctx).seed
+    per = n // G
+    pieces = [ctx.to_device(ev[r * per * D:(r + 1) * per * D]) for r in range(G)]
+    coins = [ctx.to_device(image) for _ in range(G)]
+    torch.cuda.synchronize()
+    out, errs = [None] * G, []
+
+    def run(r):
+        try:
+            out[r] = parallel.comm_sharded_fri_build_layers(lib, comms[r], rank_ctx[r], hasher, opts, pieces[r], D, coins[r], min_rows_per_rank=min_rows)
+            rank_ctx[r].sync()
+        except BaseException as e:        # noqa: BLE001
+            errs.append(e)
+    try:
+        ts = [threading.Thread(target=run, args=(r,)) for r in range(G)]
+        [t.start() for t in ts]
+        [t.join(timeout=300) for t in ts]
+        assert not errs, errs
+        total = opts.num_fri_layers(n)
+        assert 0 < out[0]["num_sharded"] <= total and (min_rows <= 2 or out[0]["num_sharded"] < total)
+        for r in range(G):
+            roots, alphas = ctx.to_host(out[r]["roots"]), ctx.to_host(out[r]["alphas"])
+            assert len(chan.commitments) == total + 1
+            for k in range(total + 1):
+                assert np.array_equal(roots[k], chan.commitments[k]), "rank %d, commitment %d" % (r, k)
+            for k in range(total):
+                assert np.array_equal(alphas[k], chan.alphas[k]), "rank %d, alpha %d" % (r, k)
+            assert np.array_equal(ctx.to_host(out[r]["remainder"]), single.remainder_poly)
+            st = ctx.to_host(coins[r])
+            assert np.array_equal(st[:32], chan.public_coin.seed)
+    finally:
+        for c in comms:
+            lib.wf_comm_destroy(c)
+        for c in rank_ctx:
+            c.close()

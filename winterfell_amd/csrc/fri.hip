@@ -202,7 +202,7 @@ int build_layers(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
     if (d_remainder && (blowup == 0 || (blowup & (blowup - 1)) || ((uint64_t)blowup >> (log_len - num_layers * log_nf)) > 1)) return WF_ERR_INVALID_ARG;
     for (uint32_t k = 0; k < num_layers; k++)
         if (!d_transposed[k] || !d_leaves[k] || !d_nodes[k] || !d_folded[k]) return WF_ERR_INVALID_ARG;
-    WF_TRY(layer_commit<HF>(ctx, hash, D, d_evals, log_len, folding, d_transposed[0], d_leaves[0], d_nodes[0], nullptr));
+    if (num_layers) WF_TRY(layer_commit<HF>(ctx, hash, D, d_evals, log_len, folding, d_transposed[0], d_leaves[0], d_nodes[0], nullptr));
     for (uint32_t k = 0; k < num_layers; k++) {
         void *alpha = (uint8_t *)d_alphas + (size_t)k * D * sizeof(T);
         // channel.commit_fri_layer(root) and channel.draw_fri_alpha(), one launch
@@ -242,7 +242,7 @@ extern "C" int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ex
                                    uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
                                    void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded,
                                    void *d_roots, void *d_alphas, uint32_t blowup, void *d_remainder) {
-    if (!ctx || !d_evals || !h_domain_offset || !d_coin || !d_roots || !d_alphas) return WF_ERR_INVALID_ARG;
+    if (!ctx || !d_evals || !h_domain_offset || !d_coin || !d_roots || (num_layers && !d_alphas)) return WF_ERR_INVALID_ARG;
     if (num_layers == 0 && !d_remainder) return WF_OK;
     if (num_layers && (!d_transposed || !d_leaves || !d_nodes || !d_folded)) return WF_ERR_INVALID_ARG;
 #define WF_BL(HF) return build_layers<HF>(ctx, hash, ext_degree, d_evals, log_len, folding, num_layers, h_domain_offset, d_coin, d_transposed, d_leaves, \

@@ -598,3 +598,58 @@ def emulated_partitioned_fri(backends_factory, options, channel_factory, evaluat
         _, rem = backend.finish_unsharded(_TailOptions(options, 0), channels[k], vector.clone())
         results[k]["remainder"] = rem
     return results, channels
+
+
+# ---- the same FRI sharding entirely behind the C ABI (wf_comm_*: RCCL or loopback transport, no torch.distributed) ----------------
+def comm_sharded_fri_build_layers(lib, comm, ctx, hasher, options, piece, ext_degree, coin_state, min_rows_per_rank=2):
+    """FriProver::build_layers for one rank of a `wf_comm` communicator (include/winterfell_hip.h: wf_comm_sharded_fri_layers for
+    the layers that stay sharded, wf_comm_all_gather of the last pieces, wf_fri_build_layers for the small layers and the
+    remainder — unsharded, redundantly on every rank).  `comm`: the rank's wf_comm handle (ctypes.c_void_p) whose context is
+    `ctx`; `piece`: the rank's contiguous 1/G of the evaluations (device tensor); `coin_state`: the rank's 64-byte copy of the
+    device coin (identical on every rank, updated in place).  Call it on every rank (one thread or process per rank).
+    Returns dict(layers = [dict(rows, leaves, nodes, top, folded)] per sharded layer, tail = dict(transposed, leaves, nodes) per
+    unsharded layer, roots (all layers + the remainder commitment), alphas, remainder) as device tensors."""
+    import ctypes
+
+    from ._lib import _check, ptr
+    f, N, D = options.field, options.folding_factor, ext_degree
+    G, rank = lib.wf_comm_size(comm), lib.wf_comm_rank(comm)
+    ew = D * f.W
+    length = piece.numel() // ew * G
+    total_layers = options.num_fri_layers(length)
+    ns, l = 0, length
+    while ns < total_layers and (l // N) // G >= max(min_rows_per_rank, 2) and (l // N) % G == 0:
+        ns += 1
+        l //= N
+    off = f.element_words(int(options.domain_offset()))
+    off_p = off.ctypes.data_as(ctypes.c_void_p)
+    layers, l = [], length
+    for _ in range(ns):
+        rl = l // N // G
+        layers.append(dict(rows=ctx.empty_u64(rl, N * ew), leaves=ctx.empty_u8(rl, 32), nodes=ctx.empty_u8(rl, 32), top=ctx.empty_u8(G, 32),
+                           folded=ctx.empty_u64(rl * ew)))
+        l //= N
+    nt = total_layers - ns
+    roots, alphas = ctx.empty_u8(total_layers + 1, 32), ctx.empty_u64(max(total_layers, 1), ew)
+    arr = lambda key, seq: (ctypes.c_void_p * max(len(seq), 1))(*[d[key].data_ptr() for d in seq])
+    ctx.use_torch_stream()
+    if ns:
+        _check(lib.wf_comm_sharded_fri_layers(comm, hasher.HASH_ID, f.ID, D, ptr(piece), length.bit_length() - 1, N, ns, off_p, ptr(coin_state),
+                                              arr("rows", layers), arr("leaves", layers), arr("nodes", layers), arr("top", layers), arr("folded", layers),
+                                              ptr(roots), ptr(alphas)), "wf_comm_sharded_fri_layers")
+        piece = layers[-1]["folded"]
+    # the vector of the first unsharded layer, on every rank
+    vector = ctx.empty_u64(l * ew)
+    if G > 1:
+        _check(lib.wf_comm_all_gather(comm, ptr(piece), ptr(vector), (l // G) * ew * 8), "wf_comm_all_gather")
+    else:
+        vector.copy_(piece.reshape(-1))
+    tail, tl = [], l
+    for _ in range(nt):
+        tl //= N
+        tail.append(dict(transposed=ctx.empty_u64(tl, N * ew), leaves=ctx.empty_u8(tl, 32), nodes=ctx.empty_u8(tl, 32), folded=ctx.empty_u64(tl * ew)))
+    rem_size = tl // options.blowup_factor
+    remainder = ctx.empty_u64(rem_size, ew)
+    ctx.call("wf_fri_build_layers", hasher.HASH_ID, f.ID, D, ptr(vector), l.bit_length() - 1, N, nt, off_p, ptr(coin_state), arr("transposed", tail),
+             arr("leaves", tail), arr("nodes", tail), arr("folded", tail), ptr(roots[ns:]), ptr(alphas[ns:]), options.blowup_factor, ptr(remainder))
+    return dict(layers=layers, tail=tail, roots=roots, alphas=alphas[:total_layers], remainder=remainder, num_sharded=ns)
