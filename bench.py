@@ -52,6 +52,25 @@ def spawn_ranks(args):
     sys.exit(subprocess.call(cmd, env=env))
 
 
+def spin_up(fn, sync, min_s=2.0, max_s=8.0, tol=0.02, block=8):
+    """Bring the chip to the clocks it sustains under `fn` BEFORE anything is timed: the first steps after an idle period run at
+    lower clocks (round 3: the driver's `--warmup 5` measured every workload 7-20 % slower than the same binary after 50 steps).
+    Runs blocks of `block` calls until at least `min_s` seconds have passed AND three consecutive block times agree within `tol`
+    (or `max_s` is reached).  Returns (seconds spent, converged, last block ms per call).  Outside every timed region."""
+    t_start = time.perf_counter()
+    hist = []
+    while True:
+        t1 = time.perf_counter()
+        for _ in range(block):
+            fn()
+        sync()
+        hist.append((time.perf_counter() - t1) / block)
+        el = time.perf_counter() - t_start
+        ok = len(hist) >= 3 and max(hist[-3:]) <= (1.0 + tol) * min(hist[-3:])
+        if (el >= min_s and ok) or el >= max_s:
+            return el, ok, hist[-1] * 1e3
+
+
 def comm_abi_legs(ctx, dist, rank, world, barrier, timeout_s=240.0, log_rows=22, total_cols=64, fri_log_len=24):
     """BASELINE configs[3] and configs[4] on N ranks through the product's multi-GPU C ABI (include/winterfell_hip.h wf_comm_*,
     INTEGRATION.md section 6): rank 0's wf_comm_get_unique_id travels over the existing process group, every rank calls
@@ -206,6 +225,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--log-n", type=int, default=24)
+    ap.add_argument("--spinup-s", type=float, default=2.0,
+                    help="seconds of untimed steps before --warmup, until the step time is steady (0 = none); reported as spinup_s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
     ap.add_argument("--dry-run", action="store_true",
@@ -279,6 +300,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # steady clocks first (not part of --warmup, not timed): see spin_up
+    spinup_s, spinup_ok, _ = spin_up(step, torch.cuda.synchronize, min_s=args.spinup_s) if args.spinup_s > 0 else (0.0, False, None)
     for _ in range(args.warmup):
         step()
     barrier()
@@ -305,6 +328,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "spinup_s": round(spinup_s, 3), "spinup_converged": bool(spinup_ok),
         "higher_is_better": True,
         **({"INVALID": "timing experiment: results not checked"} if experiment else {}),
         "scaling": "weak",
@@ -449,22 +473,36 @@ def main():
 
     if rank == 0:
         # ---- roofline: per-kernel durations from HIP events on the launch stream (wf_prof_*) ----
-        ctx.prof_enable(True)
-        reps = max(5, min(args.steps, 20))
+        fwd = lambda: fft.evaluate_poly(data)
+        spin_up(fwd, torch.cuda.synchronize, min_s=0.5, max_s=3.0)
+        # the shader clock WHILE the transform's kernels run: a probe wavefront on its own stream beside 40 queued transforms
+        sclk_mhz = None
+        try:
+            for _ in range(40):
+                fwd()
+            sclk_mhz = ctx.shader_clock_mhz(2000)
+            torch.cuda.synchronize()
+        except Exception:
+            sclk_mhz = None
+        reps = 20
+        per_rep = []
         for _ in range(reps):
-            fft.evaluate_poly(data)
-        prof = ctx.prof_collect()
+            ctx.prof_enable(True)
+            fwd()
+            pr = ctx.prof_collect()
+            per_rep.append(pr)
         ctx.prof_enable(False)
-        kern = {k: {"launches": c, "avg_us": ms * 1e3 / c} for k, (c, ms) in prof.items()}
-        total_ms = sum(ms for _, ms in prof.values())
-        fwd_us = total_ms * 1e3 / reps
+        names = sorted({k for pr in per_rep for k in pr})
+        kern = {k: {"launches": per_rep[0].get(k, (0, 0.0))[0],
+                    "avg_us": float(np.median([pr[k][1] * 1e3 / pr[k][0] for pr in per_rep if k in pr]))} for k in names}
+        fwd_us = float(np.median([sum(ms for _, ms in pr.values()) * 1e3 for pr in per_rep]))
         alg_bytes = 2.0 * n * 8                         # read once + write once per transform
         achieved = alg_bytes / (fwd_us * 1e-6) / 1e9
         # HBM bytes per transform and the VALU counters from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE x2 per
         # the gfx950 correction + WRITE_SIZE, summed over the transform's launches); only valid for the profiled size
         traffic, valu, pmc_round = None, None, None
         try:
-            pmc_round = next(r for r in ("r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
+            pmc_round = next(r for r in ("r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
             with open(os.path.join(ROOT, "profiles", pmc_round, "bench_pmc_summary.json")) as f:
                 pmf = json.load(f)
             if args.log_n == 24:
@@ -479,9 +517,13 @@ def main():
                     insts += per_transform * cs["SQ_INSTS_VALU"]["avg"] * 64 / n
                     act += per_transform * cs["SQ_ACTIVE_INST_VALU"]["avg"] * 4
                 if insts:
+                    ghz = (sclk_mhz or 2400.0) * 1e-3
                     valu = {"insts_per_element_per_transform": insts, "active_simd_cycles_per_transform": act,
-                            "active_frac": act / (1024 * fwd_us * 1e-6 * 2.4e9), "clock_assumed_ghz": 2.4,
-                            "issue_floor_us_at_100pct": act / (1024 * 2.4e9) * 1e6,
+                            "clock_ghz": ghz, "clock_source": "measured beside the kernels (wf_debug_shader_clock: s_memtime over s_memrealtime)"
+                            if sclk_mhz else "assumed (maximum clock; the probe failed)",
+                            "active_frac": act / (1024 * fwd_us * 1e-6 * ghz * 1e9),
+                            "issue_floor_us_at_100pct": act / (1024 * ghz * 1e9) * 1e6,
+                            "active_frac_at_2.4ghz": act / (1024 * fwd_us * 1e-6 * 2.4e9),
                             "source": "profiles/%s/bench_pmc_summary.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU x 4 cycles)" % pmc_round}
         except Exception:
             traffic = None
@@ -498,14 +540,17 @@ def main():
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
+            "sclk_mhz_under_load": sclk_mhz, "reps": reps, "statistic": "median over reps of the summed kernel durations of one transform",
         }
 
         if not args.no_extra:
             ex = {}
 
-            def timed(fn, reps=5):
+            def timed(fn, reps=10):
                 fn()
                 torch.cuda.synchronize()
+                spin_up(fn, torch.cuda.synchronize, min_s=0.4, max_s=2.5, block=2)      # steady clocks for THIS leg too (untimed)
+                reps = max(reps, 10)
                 ts = []
                 for _ in range(reps):
                     t1 = time.perf_counter()
@@ -576,24 +621,52 @@ def main():
 
             # ---- HBM rooflines of the other reported rates: algorithmic bytes (SURVEY 8d / BASELINE.md section 4) over the
             # summed kernel durations (HIP events on the launch stream, wf_prof_*) of one call ----
-            def kernel_ms(fn, reps=3):
+            last_clock = [None]
+
+            def kernel_ms(fn, reps=10):
+                """median over >= 10 calls of the summed kernel durations of one call (HIP events on the launch stream), steady clocks"""
                 fn()
-                ctx.prof_enable(True)
-                for _ in range(reps):
+                spin_up(fn, torch.cuda.synchronize, min_s=0.4, max_s=2.5, block=2)
+                try:                                   # shader clock under THIS leg's load (probe wavefront beside queued calls)
                     fn()
-                prof = ctx.prof_collect()
+                    fn()
+                    last_clock[0] = ctx.shader_clock_mhz(1000)
+                    torch.cuda.synchronize()
+                except Exception:
+                    last_clock[0] = None
+                reps = max(reps, 10)
+                runs = []
+                for _ in range(reps):
+                    ctx.prof_enable(True)
+                    fn()
+                    runs.append(ctx.prof_collect())
                 ctx.prof_enable(False)
-                return sum(ms for _, ms in prof.values()) / reps, {k: round(ms * 1e3 / reps, 1) for k, (c, ms) in prof.items()}
+                tot = float(np.median([sum(ms for _, ms in pr.values()) for pr in runs]))
+                names = sorted({k for pr in runs for k in pr})
+                return tot, {k: round(float(np.median([pr[k][1] for pr in runs if k in pr])) * 1e3, 1) for k in names}
 
             # HBM bytes per call of these workloads from the committed counter runs (tools/pmc_workloads.py under rocprofv3 --pmc
             # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 per the gfx950 correction; tools/summarize_workloads_pmc.py)
             wl_traffic, wl_round = {}, None
             try:
-                wl_round = next(r for r in ("r03",) if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
+                wl_round = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
                 with open(os.path.join(ROOT, "profiles", wl_round, "workloads_pmc_summary.json")) as f:
                     wl_traffic = json.load(f)["workloads"]
             except Exception:
                 wl_traffic = {}
+
+            def issue(key, ms):
+                """the VALU issue ceiling of a workload from its committed counter run: SQ_ACTIVE_INST_VALU x 4 cycles over the 1024 SIMDs
+                at the clock measured under the leg's load = the kernel time at 100 % issue utilisation; `active_frac` = how much of the
+                measured kernel time that is.  None without a counter run."""
+                sq = wl_traffic.get(key, {}).get("sq") if key else None
+                if not sq or not sq.get("SQ_ACTIVE_INST_VALU"):
+                    return None
+                ghz = (last_clock[0] or 2400.0) * 1e-3
+                floor_ms = sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * ghz * 1e9) * 1e3
+                return {"valu_insts_per_call": sq.get("SQ_INSTS_VALU"), "active_simd_cycles_per_call": sq["SQ_ACTIVE_INST_VALU"] * 4,
+                        "clock_ghz": ghz, "clock_measured": last_clock[0] is not None, "issue_floor_ms_at_100pct": floor_ms,
+                        "active_frac": floor_ms / ms, "source": "profiles/%s/workloads_pmc_summary.json" % wl_round}
 
             def roof(alg_bytes, ms, kernels_us, what, key=None):
                 gbs = alg_bytes / (ms * 1e-3) / 1e9
@@ -601,7 +674,8 @@ def main():
                 return {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                         "algorithmic_bytes": alg_bytes, "kernel_ms": ms, "kernels_us_per_call": kernels_us, "what": what,
                         "traffic": tr, "traffic_over_algorithmic": (tr / alg_bytes) if tr else None,
-                        "traffic_source": ("profiles/%s/workloads_pmc_summary.json" % wl_round) if tr else None}
+                        "traffic_source": ("profiles/%s/workloads_pmc_summary.json" % wl_round) if tr else None,
+                        "sclk_mhz_under_load": last_clock[0], "valu": issue(key, ms)}
 
             rl = {}
             lde_what = "n c s (2 + b) + 64 b n: read trace, write polys + LDE + leaves + nodes"
@@ -639,18 +713,15 @@ def main():
             cm_r = prover.ColMatrix(ctx.to_device(rng.integers(0, fields.M, (tc, tn), dtype=np.uint64)))
             ms_r, ks_r = kernel_ms(lambda: prover.build_trace_commitment(crypto.Rp64_256, cm_r, prover.StarkDomain(tn, tb)), 2)
             hash_ms = sum(v for k, v in ks_r.items() if "ntt" not in k and "transpose" not in k) * 1e-3
-            modmul_ceiling = 2.4e12     # Montgomery products per second, whole chip: tools/microbench_field.hip "mul (rows)" 2.37e12,
-            #                             tools/microbench_sqr.hip squarings 2.30e12 (profiles/r03/microbench_sqr.txt)
             rl["lde_commit_2^20x4_b8_f64_rp64"] = {
                 "bound": "valu", "kernel_ms": ms_r, "kernels_us_per_call": ks_r, "permutations": perms, "hash_kernel_ms": hash_ms,
-                "rp64_permutations_per_s": perms / (hash_ms * 1e-3), "modmuls_per_permutation": 6384,
-                "modmuls_per_s": 6384 * perms / (hash_ms * 1e-3), "modmul_ceiling_per_s": modmul_ceiling,
-                "frac_of_modmul_ceiling": 6384 * perms / (hash_ms * 1e-3) / modmul_ceiling,
-                "what": "Rp64_256: 7 rounds x (12 S-boxes x^7 + 12 inverse S-boxes x^(1/7) + 2 MDS) = 6384 modular multiplications per permutation "
-                        "(SURVEY 8d); the ceiling is the chip's measured Montgomery-product rate (a fraction slightly above 1 is possible: the "
-                        "6384 count prices the shift-only MDS layers as multiplications)"}
+                "rp64_permutations_per_s": perms / (hash_ms * 1e-3), "sclk_mhz_under_load": last_clock[0],
+                "valu": issue("lde_commit_2^20x4_b8_f64_rp64", ms_r),
+                "what": "Rp64_256: one permutation per row (4 elements < rate 8) + one per Merkle merge.  The bound is VALU issue: `valu` "
+                        "is the issue floor of the whole call from its counter run (SQ_ACTIVE_INST_VALU x 4 cycles over 1024 SIMDs at the "
+                        "measured clock) and the fraction of the kernel time it accounts for.  (Round 3 quoted a 'modmul ceiling' fraction "
+                        "of 1.05: 6384 products per permutation priced the shift-only MDS layers as products — not a ceiling, dropped.)"}
             ex["rp64_permutations_per_s"] = rl["lde_commit_2^20x4_b8_f64_rp64"]["rp64_permutations_per_s"]
-            ex["rp64_frac_of_modmul_ceiling"] = rl["lde_commit_2^20x4_b8_f64_rp64"]["frac_of_modmul_ceiling"]
             del cm_r
             lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
             ms, ks = kernel_ms(lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))
@@ -689,44 +760,78 @@ def main():
             # body; the transform runs in place at the bench's own size.  The reference's 4-step
             # transposes are single-threaded (math/src/fft/concurrent.rs:177-218) and so are ours.
             import oracle
-            nthreads = int(os.environ.get("OMP_NUM_THREADS", "0")) or (os.cpu_count() or 1)
+            ncpu = os.cpu_count() or 1
+            env_threads = int(os.environ.get("OMP_NUM_THREADS", "0"))
+            # the reference's Rayon pool is as wide as the host; a 256-thread team is not automatically the fastest for these sizes, so
+            # every number is the BEST over team sizes {8, 32, 64, all} (round-3 review), buffers allocated and touched before the clock
+            # starts, one untimed call first
+            teams = sorted({t for t in (8, 32, 64, ncpu) if t <= ncpu}) if not env_threads else [env_threads]
             cn = n
             cp = host.copy()
             tw, itw = oracle.get_twiddles(cn), oracle.get_inv_twiddles(cn)
             oracle.evaluate_poly(cp[:1 << 16], par=True)          # load the library, spin up the OpenMP pool
-            t1 = time.perf_counter()
-            reps_cpu = 0
-            while reps_cpu < 1 or (time.perf_counter() - t1 < 10.0 and reps_cpu < 8):
-                oracle.evaluate_poly(cp, par=True, twiddles=tw, inplace=True)
+            best = None
+            per_team = {}
+            for tcount in teams:
+                oracle.set_num_threads(tcount)
+                oracle.evaluate_poly(cp, par=True, twiddles=tw, inplace=True)         # untimed: pool of this size, pages, caches
                 oracle.interpolate_poly(cp, par=True, twiddles=itw, inplace=True)
-                reps_cpu += 1
-            cpu_s = time.perf_counter() - t1
+                t1 = time.perf_counter()
+                reps_cpu = 0
+                while reps_cpu < 1 or (time.perf_counter() - t1 < 2.5 and reps_cpu < 4):
+                    oracle.evaluate_poly(cp, par=True, twiddles=tw, inplace=True)
+                    oracle.interpolate_poly(cp, par=True, twiddles=itw, inplace=True)
+                    reps_cpu += 1
+                rate = 2.0 * cn * reps_cpu / (time.perf_counter() - t1)
+                per_team[str(tcount)] = rate
+                if best is None or rate > best[0]:
+                    best = (rate, tcount, reps_cpu)
             assert np.array_equal(cp, host)
             cpu = {
-                "value": 2.0 * cn * reps_cpu / cpu_s, "unit": "elements/s", "cores": nthreads, "kind": "port",
-                "sample": "%d x (evaluate_poly + interpolate_poly) in place at 2^%d points, twiddles precomputed; OpenMP restatement of "
-                          "math/src/fft/concurrent.rs (oracle/fft_f64.c), %d threads" % (reps_cpu, args.log_n, nthreads),
+                "value": best[0], "unit": "elements/s", "cores": best[1], "kind": "port", "host_hardware_threads": ncpu,
+                "elements_per_s_by_threads": per_team,
+                "sample": "best of team sizes %s: %d x (evaluate_poly + interpolate_poly) in place at 2^%d points after one untimed pair, twiddles "
+                          "precomputed; OpenMP restatement of math/src/fft/concurrent.rs (oracle/fft_f64.c)" % (teams, best[2], args.log_n),
             }
             if not args.no_extra:
                 # the second metric beside its CPU path: trace LDE + commit (spans extend_execution_trace +
-                # compute_execution_trace_commitment, trace_lde/default/mod.rs:258-278) and the Merkle build, BLAKE3 (portable C)
+                # compute_execution_trace_commitment, trace_lde/default/mod.rs:258-278), the Merkle build and the FRI commit phase, BLAKE3
+                # (portable C).  Result buffers are allocated once and touched by an untimed call; best over team sizes.
                 tr = rng.integers(0, fields.M, (4, 1 << 20), dtype=np.uint64)
-                t1 = time.perf_counter()
-                oracle.build_trace_commitment(0, tr, 8, fields.new(7), par=True)
-                cpu["lde_commit_ms_2^20x4_b8_f64_blake3"] = (time.perf_counter() - t1) * 1e3
                 lvh = rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8)
-                t1 = time.perf_counter()
-                oracle.merkle_build(0, lvh, par=True)
-                cpu["merkle_blake3_leaves_per_s_2^23"] = (1 << 23) / (time.perf_counter() - t1)
-                # FRI commit phase (fri/benches/prover.rs shape of the GPU number above): all cores, DefaultProverChannel
                 evh = rng.integers(0, fields.M, (1 << 24) * 2, dtype=np.uint64)
-                t1 = time.perf_counter()
+                bufs = oracle.build_trace_commitment(0, tr, 8, fields.new(7), par=True)
+                nodes_h = oracle.merkle_build(0, lvh, par=True)
+                res_cpu = {"lde_commit_ms_2^20x4_b8_f64_blake3": {}, "merkle_blake3_leaves_per_s_2^23": {}, "fri_build_layers_ms_2^24_quad_fold4_blake3": {}}
+                for tcount in teams:
+                    oracle.set_num_threads(tcount)
+                    t1 = time.perf_counter()
+                    oracle.build_trace_commitment(0, tr, 8, fields.new(7), par=True, out=bufs)
+                    res_cpu["lde_commit_ms_2^20x4_b8_f64_blake3"][str(tcount)] = (time.perf_counter() - t1) * 1e3
+                    t1 = time.perf_counter()
+                    oracle.merkle_build(0, lvh, par=True, out=nodes_h)
+                    res_cpu["merkle_blake3_leaves_per_s_2^23"][str(tcount)] = (1 << 23) / (time.perf_counter() - t1)
+                # FRI commit phase (fri/benches/prover.rs shape of the GPU number above): DefaultProverChannel; one untimed call, then the
+                # two widest teams (its layers are allocated inside the call: the arena keeps them between calls)
                 oracle.fri_build_layers_par(0, evh, 4, 8, 31, fields.new(7), 2)
-                cpu["fri_build_layers_ms_2^24_quad_fold4_blake3"] = (time.perf_counter() - t1) * 1e3
+                for tcount in teams[-2:]:
+                    oracle.set_num_threads(tcount)
+                    t1 = time.perf_counter()
+                    oracle.fri_build_layers_par(0, evh, 4, 8, 31, fields.new(7), 2)
+                    res_cpu["fri_build_layers_ms_2^24_quad_fold4_blake3"][str(tcount)] = (time.perf_counter() - t1) * 1e3
+                oracle.set_num_threads(ncpu)
                 del evh
-                cpu["extras_note"] = ("one call each (buffers allocated inside the call); concurrent interpolate_columns + 8-column-segment "
-                                      "LDE + commit_to_rows + subtree-per-thread Merkle (oracle/commit.c), FRI layers with parallel transpose / "
-                                      "row hashing / folding (oracle/fri.c), portable-C BLAKE3 (the Rust crate is AVX2/AVX-512)")
+                for k, by_t in res_cpu.items():
+                    pick = max if "per_s" in k else min
+                    bt = pick(by_t, key=lambda q: by_t[q]) if "per_s" in k else min(by_t, key=lambda q: by_t[q])
+                    cpu[k] = by_t[bt]
+                    cpu[k + "_threads"] = int(bt)
+                    cpu[k + "_by_threads"] = by_t
+                cpu["extras_note"] = ("best over the team sizes, result buffers allocated and touched before the clock starts (one untimed call); "
+                                      "concurrent interpolate_columns + 8-column-segment LDE + commit_to_rows + subtree-per-thread Merkle "
+                                      "(oracle/commit.c), FRI layers with parallel transpose / row hashing / folding (oracle/fri.c), portable-C "
+                                      "BLAKE3 (the Rust crate is AVX2/AVX-512).  The reference publishes 2.5 s for the WHOLE f128 rescue proof of "
+                                      "2^20 rows on 8 laptop cores (README.md:411-465); these are f64 stages on this host")
             out["cpu_baseline"] = cpu
         print(json.dumps(out))
 

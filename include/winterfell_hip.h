@@ -19,14 +19,16 @@
  *  - Pointers named d_* are DEVICE pointers (from wf_malloc or any HIP allocation, e.g. a torch tensor);
  *    pointers named h_* are host pointers.  Work is enqueued on the context's stream; results are
  *    complete after wf_ctx_sync() (functions that return host values synchronise themselves).
- *  - A context is not re-entrant: use one context per calling thread (the reference calls these entry
- *    points from one thread at a time, prover/src/lib.rs:282-492).
+ *  - Every entry point locks its context for the duration of the call: calls on ONE context from several host threads are safe and
+ *    run one after the other (TraceLde: Sync — the reference reads frames from Rayon workers, prover/src/constraints/evaluator/
+ *    default.rs:187).  For calls that should run concurrently use one context per thread (each has its own stream, caches, pool).
  */
 #ifndef WINTERFELL_HIP_H
 #define WINTERFELL_HIP_H
 
 #include <stddef.h>
 #include <stdint.h>
+#include <sys/types.h>
 
 #ifdef __cplusplus
 extern "C" {
@@ -47,7 +49,10 @@ enum {
     WF_ERR_NO_DEVICE = 7,
     WF_ERR_ZERO_OFFSET = 8,          /* fft/mod.rs:185 "domain offset cannot be zero"                     */
     WF_ERR_NOT_FOUND = 9,            /* prover/src/channel.rs:175 "nonce not found"                        */
-    WF_ERR_COMM_ABORTED = 10         /* a peer rank of a loopback wf_comm failed: the collective was abandoned */
+    WF_ERR_COMM_ABORTED = 10,        /* a peer rank of a loopback wf_comm failed: the collective was abandoned */
+    WF_ERR_DEVICE_STATUS = 11        /* a kernel flagged a protocol failure in the context's status word (a Merkle ticket word that was
+                                        not in the state the launch expects: results of the call are not to be trusted); returned by the
+                                        next synchronising call, bits in wf_last_device_status()                          */
 };
 
 /* ---- enums ----------------------------------------------------------------------------------------- */
@@ -75,6 +80,7 @@ int wf_ctx_set_stream(wf_ctx *ctx, void *hip_stream);
 int wf_ctx_get_stream(wf_ctx *ctx, void **hip_stream);
 int wf_ctx_sync(wf_ctx *ctx);
 int wf_last_hip_error(wf_ctx *ctx);
+uint32_t wf_last_device_status(wf_ctx *ctx);
 
 /* Measurement hook (no reference counterpart; plays the role of the reference's tracing spans,
  * prover/src/trace/trace_lde/default/mod.rs:258,277): when enabled every kernel launch is bracketed by HIP events
@@ -83,11 +89,28 @@ int wf_last_hip_error(wf_ctx *ctx);
  * time of a multi-launch call without the bracket overhead (a bracket adds ~2-4 us to its launch). */
 int wf_prof_enable(wf_ctx *ctx, int on);
 int wf_prof_collect(wf_ctx *ctx, char *h_buf, size_t buf_len);
+/* Measurement hook: the shader clock in MHz while the work queued on the context's stream runs — one wavefront on a stream of its
+ * own counts shader cycles (s_memtime) over `spin_us` microseconds of the constant-rate clock (s_memrealtime).  The part clocks to its
+ * power budget; bench.py quotes its issue ceilings at this clock, not at the 2.4 GHz maximum. */
+int wf_debug_shader_clock(wf_ctx *ctx, uint32_t spin_us, double *h_mhz);
+/* Debug allocator (WF_DEBUG_GUARD=1 guard pages / 2 red zones, read once per process; 0 = off): every device allocation of the library
+ * — and, through torch's pluggable allocator pointed at the two functions below, of a test session — becomes a block of its own with
+ * unmapped pages right behind its last byte.  tests/conftest.py, tools/guard_session.sh. */
+void *wf_debug_torch_malloc(ssize_t size, int device, void *stream);
+void wf_debug_torch_free(void *ptr, ssize_t size, int device, void *stream);
+int wf_debug_guard_mode(void);
+/* Test hook: overwrite the ticket word the next one-launch Merkle tree of this context will use (the failure-detection test). */
+int wf_debug_poke_tree_ticket(wf_ctx *ctx, uint32_t value);
 
 /* Device memory for the caller's buffers.  wf_free does not synchronise: blocks go to a per-context pool and are handed out
  * again by later wf_malloc calls — safe because everything a context does is ordered on its stream (a buffer shared with
- * another stream must be synchronised by the caller before it is freed).  wf_ctx_trim returns the cached blocks to the
- * driver; wf_ctx_destroy does so implicitly. */
+ * another stream must be synchronised by the caller before it is freed).  wf_free accepts live blocks of THIS context's pool only
+ * (anything else — another context's block, a double free — is WF_ERR_INVALID_ARG; it is never passed on to hipFree).  wf_ctx_trim
+ * returns the cached blocks to the driver; wf_ctx_destroy does so implicitly, blocks the caller never freed included.
+ * wf_memcpy_h2d / wf_memcpy_d2h return after the copy.  Pageable host memory goes through page-locked bounce buffers inside the
+ * library (the runtime is never handed a pageable range: it would pin it in place and find the pinned object again by address after
+ * the buffer was freed and re-allocated — a GPU fault at a host address); ranges page-locked by wf_host_register /
+ * hipHostMalloc are copied directly at PCIe rate. */
 int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr);
 int wf_free(wf_ctx *ctx, void *d_ptr);
 int wf_ctx_trim(wf_ctx *ctx);

@@ -251,10 +251,12 @@ def merge_with_int(hasher, seed, value):
     return out
 
 
-def merkle_build(hasher, leaves, par=False):
-    """leaves: (n, 32) uint8.  Returns nodes (n, 32) uint8 in the reference heap layout (root at [1])."""
+def merkle_build(hasher, leaves, par=False, out=None):
+    """leaves: (n, 32) uint8.  Returns nodes (n, 32) uint8 in the reference heap layout (root at [1]).  `out`: a caller-owned
+    (already touched) nodes array to write into (bench.py's cpu_baseline times the build, not the page faults of a fresh buffer)."""
     lv = np.ascontiguousarray(leaves).view(np.uint8).reshape(-1, 32)
-    nodes = np.empty_like(lv)
+    nodes = np.empty_like(lv) if out is None else out
+    assert nodes.shape == lv.shape and nodes.dtype == np.uint8 and nodes.flags.c_contiguous
     fn = lib().or_merkle_build_par if par else lib().or_merkle_build
     rc = fn(ctypes.c_int(hasher), _ptr(lv), _u64(lv.shape[0]), _ptr(nodes))
     if rc:
@@ -299,16 +301,22 @@ def hash_rows(hasher, data, elements_per_row, D=1, num_partitions=1, hash_rate=1
     return leaves
 
 
-def build_trace_commitment(hasher, trace, blowup, domain_offset, D=1, num_partitions=1, hash_rate=1, par=False):
-    """trace: (c, n*D) uint64 column-major evaluations.  Returns (polys, lde, leaves, nodes)."""
-    polys = _u64arr(trace).copy()
-    c, nD = polys.shape
+def build_trace_commitment(hasher, trace, blowup, domain_offset, D=1, num_partitions=1, hash_rate=1, par=False, out=None):
+    """trace: (c, n*D) uint64 column-major evaluations.  Returns (polys, lde, leaves, nodes).  `out` = (polys, lde, leaves, nodes)
+    of a previous call: the result arrays are reused (already page-faulted) instead of freshly allocated."""
+    c, nD = _u64arr(trace).shape
     n = nD // D
     N = n * blowup
     rw = row_width(c * D)
-    lde = np.empty((N, rw), dtype=np.uint64)
-    leaves = np.empty((N, 32), dtype=np.uint8)
-    nodes = np.empty((N, 32), dtype=np.uint8)
+    if out is None:
+        polys = _u64arr(trace).copy()
+        lde = np.empty((N, rw), dtype=np.uint64)
+        leaves = np.empty((N, 32), dtype=np.uint8)
+        nodes = np.empty((N, 32), dtype=np.uint8)
+    else:
+        polys, lde, leaves, nodes = out
+        assert polys.shape == (c, nD) and lde.shape == (N, rw) and leaves.shape == (N, 32) and nodes.shape == (N, 32)
+        polys[...] = _u64arr(trace)
     rc = lib().or_build_trace_commitment(ctypes.c_int(hasher), _ptr(polys), _u64(c), _u64(n), ctypes.c_uint(D),
                                          _u64(blowup), _u64(domain_offset), _u64(num_partitions), _u64(hash_rate),
                                          _ptr(lde), _ptr(leaves), _ptr(nodes), ctypes.c_int(par))

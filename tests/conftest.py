@@ -14,6 +14,21 @@ P = 2**64 - 2**32 + 1
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu via gpurun)")
+    _guarded_session()
+
+
+def _guarded_session():
+    """WF_DEBUG_GUARD=1 (or 2): the electric-fence session.  Every device allocation of the library AND — through torch's pluggable
+    allocator, pointed at the library's wf_debug_torch_malloc / _free — every tensor the tests hand to it is a block of its own with
+    unmapped pages behind its last byte (WF_DEBUG_GUARD_ALIGN=left: before its first), so a kernel that steps outside ANY buffer is a
+    GPU page fault at that instruction, with the test's name on the screen (-v) and HIP_LAUNCH_BLOCKING=1 naming the call.  Mode 2:
+    red zones checked at free time instead (no virtual-memory API needed).  tools/guard_session.sh is the command line."""
+    if os.environ.get("WF_DEBUG_GUARD", "0") in ("", "0"):
+        return
+    import torch
+    lib = os.path.join(ROOT, "winterfell_amd", "libwinterfell_hip.so")
+    alloc = torch.cuda.memory.CUDAPluggableAllocator(lib, "wf_debug_torch_malloc", "wf_debug_torch_free")
+    torch.cuda.memory.change_current_allocator(alloc)
 
 
 @pytest.fixture(scope="session")

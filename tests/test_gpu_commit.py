@@ -109,6 +109,44 @@ def test_merkle_vs_oracle(wf, oracle, log_n):
         assert np.array_equal(crypto.MerkleTree.new(crypto.Rp64_256, lv).nodes, oracle.merkle_build(1, lv, par=True)), log_n
 
 
+def test_a_corrupted_merkle_ticket_is_reported_not_swallowed(wf, oracle):
+    """Failure detection of the one-launch tree (round-3 review): merkle_finish_kernel's workgroups meet on a ticket word; a word that
+    is not in the state the launch expects used to make the kernel skip the top of the tree SILENTLY.  Now the ticket carries its
+    epoch, the kernel flags the context's status word, and the next synchronising call returns WF_ERR_DEVICE_STATUS; the ring is reset,
+    so the tree after that is right again."""
+    from winterfell_amd._lib import WfError
+    ctx, crypto, _, _ = wf
+    lv = np.random.default_rng(77).integers(0, 256, (1 << 13, 32), dtype=np.uint8)
+    want = oracle.merkle_build(0, lv, par=True)
+    assert np.array_equal(crypto.MerkleTree.new(crypto.Blake3_256, lv).nodes, want)
+    for garbage in (0xDEADBEEF, 3):              # a foreign epoch; the right epoch with arrivals already counted
+        ctx.call("wf_debug_poke_tree_ticket", garbage)
+        tree = crypto.MerkleTree.new(crypto.Blake3_256, lv)
+        with pytest.raises(WfError) as ei:
+            ctx.sync()
+        assert ei.value.status == 11, ei.value
+        assert ctx.lib.wf_last_device_status(ctx.handle) & 1
+        del tree
+        assert np.array_equal(crypto.MerkleTree.new(crypto.Blake3_256, lv).nodes, want)      # the ring was put back: clean again
+        ctx.sync()
+
+
+def test_wf_free_refuses_what_is_not_a_live_block_of_the_pool(wf):
+    """wf_free used to pass an unknown pointer on to hipFree (another owner's memory pulled from under it); now it is an error."""
+    import ctypes
+    from winterfell_amd._lib import WfError
+    ctx = wf[0]
+    p = ctypes.c_void_p()
+    ctx.call("wf_malloc", 4096, ctypes.byref(p))
+    t = ctx.empty_u8(4096)
+    with pytest.raises(WfError):
+        ctx.call("wf_free", ctypes.c_void_p(t.data_ptr()))        # a torch tensor's memory
+    ctx.call("wf_free", p)
+    with pytest.raises(WfError):
+        ctx.call("wf_free", p)                                     # double free
+    assert int(t.sum()) >= 0                                       # the tensor is still there
+
+
 def test_merkle_errors(wf):
     ctx, crypto, _, _ = wf
     with pytest.raises(crypto.MerkleTreeError, match="TooFewLeaves"):

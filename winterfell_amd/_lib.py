@@ -25,6 +25,9 @@ _PROTOS = {
     "wf_ctx_get_stream": [_vp, ctypes.POINTER(_vp)],
     "wf_ctx_sync": [_vp],
     "wf_last_hip_error": [_vp],
+    "wf_last_device_status": [_vp],
+    "wf_debug_shader_clock": [_vp, _u32, ctypes.POINTER(ctypes.c_double)],
+    "wf_debug_poke_tree_ticket": [_vp, _u32],
     "wf_prof_enable": [_vp, _int],
     "wf_prof_collect": [_vp, ctypes.c_char_p, ctypes.c_size_t],
     "wf_malloc": [_vp, ctypes.c_size_t, ctypes.POINTER(_vp)],
@@ -120,6 +123,7 @@ def load_library():
             lib.wf_version.restype = _int
             lib.wf_row_width.argtypes = [_u32, _u32]
             lib.wf_row_width.restype = _u64
+            lib.wf_last_device_status.restype = _u32
             _lib = lib
     return _lib
 
@@ -172,16 +176,24 @@ class Context:
 
     # ---- buffers --------------------------------------------------------------------------------------
     def to_device(self, arr):
-        """numpy uint64/uint8 array (or torch tensor) -> torch tensor in HBM (int64 / uint8 bit containers)."""
+        """numpy uint64/uint8 array (or torch tensor) -> torch tensor in HBM (int64 / uint8 bit containers).  Host data crosses
+        through wf_memcpy_h2d — the library's page-locked bounce buffers — never through a runtime copy out of PAGEABLE memory:
+        ROCclr pins such a range in place and finds the pinned object again by address alone after the buffer was freed and
+        re-allocated (a GPU page fault at a host address, see csrc/context.hip and DESIGN.md section 9)."""
         torch = _torch()
         if isinstance(arr, torch.Tensor):
-            return arr.to(self.device).contiguous()
+            if arr.device.type == "cuda":
+                return arr.to(self.device).contiguous()
+            arr = arr.numpy()
         a = np.ascontiguousarray(arr)
         if a.dtype == np.uint64:
             a = a.view(np.int64)
         elif a.dtype != np.uint8 and a.dtype != np.int64:
             raise TypeError("expected uint64 / uint8 data, got %s" % a.dtype)
-        return torch.from_numpy(a).to(self.device)
+        out = torch.empty(a.shape, dtype=torch.int64 if a.dtype == np.int64 else torch.uint8, device=self.device)
+        if a.nbytes:
+            self.call("wf_memcpy_h2d", _vp(out.data_ptr()), _vp(a.ctypes.data), a.nbytes)
+        return out
 
     def empty_u64(self, *shape):
         return _torch().empty(shape, dtype=_torch().int64, device=self.device)
@@ -189,10 +201,26 @@ class Context:
     def empty_u8(self, *shape):
         return _torch().empty(shape, dtype=_torch().uint8, device=self.device)
 
-    @staticmethod
-    def to_host(t):
-        a = t.detach().cpu().numpy()
+    def to_host(self, t):
+        """device tensor -> numpy array (uint64 view of the int64 bit container), through wf_memcpy_d2h (see to_device)."""
+        torch = _torch()
+        t = t.detach()
+        if t.device.type != "cuda":
+            a = t.numpy()
+            return a.view(np.uint64) if a.dtype == np.int64 else a
+        if t.dtype not in (torch.int64, torch.uint8):
+            raise TypeError("expected an int64 / uint8 tensor, got %s" % t.dtype)
+        t = t.contiguous()
+        a = np.empty(tuple(t.shape), dtype=np.int64 if t.dtype == torch.int64 else np.uint8)
+        if a.nbytes:
+            self.call("wf_memcpy_d2h", _vp(a.ctypes.data), _vp(t.data_ptr()), a.nbytes)
         return a.view(np.uint64) if a.dtype == np.int64 else a
+
+    def shader_clock_mhz(self, spin_us=500):
+        """the shader clock while the work already queued on this context's stream runs (wf_debug_shader_clock)"""
+        mhz = ctypes.c_double(0.0)
+        self.call("wf_debug_shader_clock", spin_us, ctypes.byref(mhz))
+        return float(mhz.value)
 
     def prof_enable(self, on=True):
         """True / 1: every launch bracketed by events; 2: one event pair around all the launches until prof_collect ("__span__")"""

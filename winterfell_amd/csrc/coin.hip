@@ -122,18 +122,18 @@ int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t 
 }  // namespace
 
 extern "C" int wf_coin_init(wf_ctx *ctx, void *d_coin, const void *h_seed) {
+    WF_ENTER(ctx);
     if (!ctx || !d_coin || !h_seed) return WF_ERR_INVALID_ARG;
     CoinState st;
     memset(&st, 0, sizeof(st));
     memcpy(st.seed, h_seed, 32);
     uint8_t image[WF_COIN_BYTES] = {0};
     memcpy(image, &st, sizeof(st));
-    WF_HIP(hipMemcpyAsync(d_coin, image, WF_COIN_BYTES, hipMemcpyHostToDevice, ctx->stream));
-    WF_HIP(hipStreamSynchronize(ctx->stream));    // `image` is on this frame
-    return WF_OK;
+    return wf_copy_h2d(ctx, d_coin, image, WF_COIN_BYTES);    // synchronises: `image` is on this frame
 }
 
 extern "C" int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d_digest, void *d_digest_copy) {
+    WF_ENTER(ctx);
     if (!ctx || !d_coin || !d_digest) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     wf_prof_begin(ctx, "coin");
@@ -148,6 +148,7 @@ extern "C" int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d
 }
 
 extern "C" int wf_coin_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, uint32_t count, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_coin || !d_out) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     const uint32_t max_ext = field == WF_FIELD_F128 ? 2 : 3;       // 32 digest bytes hold two f128 or three 64-bit elements
@@ -163,6 +164,7 @@ extern "C" int wf_coin_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degre
 
 extern "C" int wf_coin_reseed_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, const void *d_digest, void *d_digest_copy,
                                   void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_coin || !d_digest || !d_out) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
@@ -178,10 +180,11 @@ extern "C" int wf_coin_reseed_draw(wf_ctx *ctx, int hash, int field, uint32_t ex
 }
 
 extern "C" int wf_coin_read(wf_ctx *ctx, const void *d_coin, void *h_seed, uint64_t *h_counter) {
+    WF_ENTER(ctx);
     if (!ctx || !d_coin || !h_seed || !h_counter) return WF_ERR_INVALID_ARG;
     CoinState st;
-    WF_HIP(hipMemcpyAsync(&st, d_coin, sizeof(st), hipMemcpyDeviceToHost, ctx->stream));
-    WF_HIP(hipStreamSynchronize(ctx->stream));
+    WF_TRY(wf_copy_d2h(ctx, &st, d_coin, sizeof(st)));
+    WF_TRY(wf_check_status(ctx));
     memcpy(h_seed, st.seed, 32);
     *h_counter = st.counter;
     return st.failed ? WF_ERR_NOT_FOUND : WF_OK;

@@ -129,8 +129,15 @@ struct CommScope {
             }
     }
     ~CommScope() {
+        if (!ok && loop) {
+            // error exit of a loopback rank: release the peers FIRST, and keep this rank's temporaries allocated — a peer that is past
+            // the first barrier of a collective may still be copying from them on its own stream.  They stay live blocks of the
+            // context's pool and go back to the driver with wf_ctx_destroy.  After WF_ERR_COMM_ABORTED the communicator is dead:
+            // every rank destroys its wf_comm and a new one is created (include/winterfell_hip.h).
+            loop->bar.abort();
+            return;
+        }
         for (void *p : blocks) (void)wf_free(ctx, p);
-        if (!ok && loop) loop->bar.abort();
     }
 };
 
@@ -154,6 +161,7 @@ extern "C" int wf_comm_get_unique_id(uint8_t *id) {
 }
 
 extern "C" int wf_comm_init_rank(wf_ctx *ctx, const uint8_t *id, int rank, int world, wf_comm **out) {
+    WF_ENTER(ctx);
     if (!ctx || !id || !out || world < 1 || rank < 0 || rank >= world) return WF_ERR_INVALID_ARG;
     Rccl &r = rccl();
     if (!r.ok) return WF_ERR_UNSUPPORTED;
@@ -206,6 +214,7 @@ extern "C" int wf_comm_size(const wf_comm *cm) { return cm ? cm->world : -1; }
 extern "C" int wf_comm_all_gather(wf_comm *cm, const void *d_send, void *d_recv, uint64_t bytes) {
     if (!cm || !d_send || !d_recv || bytes == 0) return WF_ERR_INVALID_ARG;
     wf_ctx *ctx = cm->ctx;
+    std::lock_guard<std::recursive_mutex> wf_lock_(ctx->mu);    // a rank thread holds only its own context's lock across the barriers
     if (cm->nccl) {
         if (rccl().AllGather(d_send, d_recv, bytes, /*ncclUint8*/ 1, cm->nccl, ctx->stream) != 0) return WF_ERR_HIP;
         return WF_OK;
@@ -239,6 +248,7 @@ extern "C" int wf_comm_all_gather(wf_comm *cm, const void *d_send, void *d_recv,
 extern "C" int wf_comm_all_to_all(wf_comm *cm, const void *d_send, void *d_recv, uint64_t bytes) {
     if (!cm || !d_send || !d_recv || bytes == 0 || d_send == d_recv) return WF_ERR_INVALID_ARG;
     wf_ctx *ctx = cm->ctx;
+    std::lock_guard<std::recursive_mutex> wf_lock_(ctx->mu);    // a rank thread holds only its own context's lock across the barriers
     if (cm->nccl) {
         if (rccl().AllToAll(d_send, d_recv, bytes, 1, cm->nccl, ctx->stream) != 0) return WF_ERR_HIP;
         return WF_OK;
@@ -292,6 +302,7 @@ extern "C" int wf_comm_sharded_commit(wf_comm *cm, int hash, int field, uint32_t
                                       void *d_lde_shard, void *d_leaves, void *d_nodes, void *d_top, void *h_root) {
     if (!cm || !d_trace_shard || !d_lde_shard || !d_leaves || !d_nodes || !d_top || shard_cols == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
     wf_ctx *ctx = cm->ctx;
+    std::lock_guard<std::recursive_mutex> wf_lock_(ctx->mu);    // a rank thread holds only its own context's lock across the barriers
     const uint32_t G = (uint32_t)cm->world;
     const uint64_t N = 1ull << (log_n + log_blowup);
     if (G & (G - 1)) return WF_ERR_NOT_POWER_OF_TWO;     // the sub-trees must tile a binary tree
@@ -372,6 +383,7 @@ extern "C" int wf_comm_sharded_fri_layers(wf_comm *cm, int hash, int field, uint
     if (folding != 2 && folding != 4 && folding != 8 && folding != 16) return WF_ERR_UNSUPPORTED;
     if (field != WF_FIELD_F64 && field != WF_FIELD_F128 && field != WF_FIELD_F62) return WF_ERR_UNSUPPORTED;
     wf_ctx *ctx = cm->ctx;
+    std::lock_guard<std::recursive_mutex> wf_lock_(ctx->mu);    // a rank thread holds only its own context's lock across the barriers
     const uint32_t G = (uint32_t)cm->world, r = (uint32_t)cm->rank, N = folding;
     if (G & (G - 1)) return WF_ERR_NOT_POWER_OF_TWO;
     uint32_t log_nf = 0, log_g = 0;

@@ -572,23 +572,24 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
       *d_ccb = d_aval + a_val.size(), *d_cct = d_ccb + cc_b.size(), *d_xval = d_cct + cc_t.size(), *d_ccx = d_xval + x_val.size(),
       *d_rnd = d_ccx + cc_x.size();
     uint32_t *d_acol = (uint32_t *)(d_rnd + rnd.size()), *d_agrp = d_acol + num_assert, *d_xcol = d_agrp + num_assert, *d_xgrp = d_xcol + x_col.size();
-    auto up = [&](void *dst, const void *src, size_t nbytes) { return hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream); };
-    WF_HIP(up(d_ptab, ptab.data(), ptab.size() * sizeof(T)));
-    WF_HIP(up(d_zt, zt.data(), zt.size() * sizeof(T)));
-    WF_HIP(up(d_b, bvals.data(), bvals.size() * sizeof(T)));
-    WF_HIP(up(d_aval, a_val.data(), a_val.size() * sizeof(T)));
-    WF_HIP(up(d_ccb, cc_b.data(), cc_b.size() * sizeof(T)));
-    WF_HIP(up(d_cct, cc_t.data(), cc_t.size() * sizeof(T)));
-    WF_HIP(up(d_acol, a_col.data(), num_assert * sizeof(uint32_t)));
-    WF_HIP(up(d_agrp, a_group.data(), num_assert * sizeof(uint32_t)));
+    WfUploadBatch batch(ctx, d_ptab);             // everything from d_ptab on is host data: one staged copy
+    auto up = [&](void *dst, const void *src, size_t nbytes) { batch.add(dst, src, nbytes); };
+    up(d_ptab, ptab.data(), ptab.size() * sizeof(T));
+    up(d_zt, zt.data(), zt.size() * sizeof(T));
+    up(d_b, bvals.data(), bvals.size() * sizeof(T));
+    up(d_aval, a_val.data(), a_val.size() * sizeof(T));
+    up(d_ccb, cc_b.data(), cc_b.size() * sizeof(T));
+    up(d_cct, cc_t.data(), cc_t.size() * sizeof(T));
+    up(d_acol, a_col.data(), num_assert * sizeof(uint32_t));
+    up(d_agrp, a_group.data(), num_assert * sizeof(uint32_t));
     if (AIR::AUX_WIDTH > 0) {
-        WF_HIP(up(d_xval, x_val.data(), x_val.size() * sizeof(T)));
-        WF_HIP(up(d_ccx, cc_x.data(), cc_x.size() * sizeof(T)));
-        WF_HIP(up(d_rnd, rnd.data(), rnd.size() * sizeof(T)));
-        WF_HIP(up(d_xcol, x_col.data(), x_col.size() * sizeof(uint32_t)));
-        WF_HIP(up(d_xgrp, x_group.data(), x_group.size() * sizeof(uint32_t)));
+        up(d_xval, x_val.data(), x_val.size() * sizeof(T));
+        up(d_ccx, cc_x.data(), cc_x.size() * sizeof(T));
+        up(d_rnd, rnd.data(), rnd.size() * sizeof(T));
+        up(d_xcol, x_col.data(), x_col.size() * sizeof(uint32_t));
+        up(d_xgrp, x_group.data(), x_group.size() * sizeof(uint32_t));
     }
-    WF_HIP(hipStreamSynchronize(ctx->stream));      // host vectors die with this frame
+    WF_TRY(batch.flush());                         // synchronises: the host vectors die with this frame
 
     SeriesTable xs;
     WF_TRY(wf_get_series_table<HF>(ctx, g_ce, off, log_ce, &xs));
@@ -660,6 +661,7 @@ extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t
                                        const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
                                        const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
                                        void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_trace_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps || !h_assert_values ||
         !h_cc_boundary || !d_out)
         return WF_ERR_INVALID_ARG;
@@ -703,6 +705,7 @@ extern "C" int wf_evaluate_constraints_aux(wf_ctx *ctx, int air, int field, uint
                                            const uint32_t *h_aux_assert_columns, const uint64_t *h_aux_assert_steps,
                                            const void *h_aux_assert_values, const void *h_cc_aux_boundary, const void *h_aux_rand_elements,
                                            void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_main_lde || !d_aux_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps ||
         !h_assert_values || !h_cc_boundary || !h_aux_rand_elements || !d_out)
         return WF_ERR_INVALID_ARG;

@@ -485,9 +485,8 @@ struct Deep {
                                log_seg, num_points, (const T *)pw, (uint64_t)PW_WORDS, d_out);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
-        WF_HIP(hipMemcpyAsync(h_out, d_out, (size_t)total * D * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
-        WF_HIP(hipStreamSynchronize(ctx->stream));
-        return WF_OK;
+        WF_TRY(wf_copy_d2h(ctx, h_out, d_out, (size_t)total * D * sizeof(T)));
+        return wf_check_status(ctx);
     }
 
     static int compose(wf_ctx *ctx, const void *d_main, uint32_t c_main, uint64_t main_stride, const void *d_aux, uint32_t c_aux,
@@ -510,8 +509,7 @@ struct Deep {
         WF_TRY(wf_scratch(ctx, 1, small_words * sizeof(T), &tmp1));
         T *S = (T *)tmp0;
         T *pw_z = (T *)tmp1, *pw_zg = pw_z + PW_WORDS, *d_cc = pw_zg + PW_WORDS, *rest = d_cc + cc.size();
-        WF_HIP(hipMemcpyAsync(d_cc, cc.data(), cc.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-        WF_HIP(hipStreamSynchronize(ctx->stream));   // cc is a stack-lifetime host buffer
+        WF_TRY(wf_copy_h2d(ctx, d_cc, cc.data(), cc.size() * sizeof(T)));   // synchronises: cc is a stack-lifetime host buffer
         WF_TRY(make_pows(ctx, z, nullptr, 0, pw_z));
         WF_TRY(make_pows(ctx, zg, nullptr, 0, pw_zg));
         wf_prof_begin(ctx, "deep_acc");
@@ -564,6 +562,7 @@ int compose_dispatch(wf_ctx *ctx, uint32_t D, const void *d_main, uint32_t c_mai
 extern "C" int wf_polys_evaluate_at(wf_ctx *ctx, int field, uint32_t poly_ext_degree, uint32_t ext_degree, const void *d_polys,
                                     uint32_t num_cols, uint64_t col_stride, uint32_t log_n, const void *h_points,
                                     uint32_t num_points, void *h_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_polys || !h_points || !h_out) return WF_ERR_INVALID_ARG;
     if (num_cols == 0 || num_points == 0) return WF_OK;
     if (col_stride < ((uint64_t)poly_ext_degree << log_n) || num_cols > 65535) return WF_ERR_INVALID_ARG;
@@ -579,6 +578,7 @@ extern "C" int wf_deep_compose(wf_ctx *ctx, int field, uint32_t ext_degree, cons
                                uint64_t main_stride, const void *d_aux_polys, uint32_t num_aux, uint64_t aux_stride,
                                const void *d_quotient_polys, uint32_t num_quotient, uint64_t quotient_stride, uint32_t log_n,
                                const void *h_z, const void *h_cc_trace, const void *h_cc_constraints, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !h_z || !d_out || log_n == 0) return WF_ERR_INVALID_ARG;
     if ((num_main && (!d_main_polys || main_stride < (1ull << log_n))) ||
         (num_aux && (!d_aux_polys || aux_stride < ((uint64_t)ext_degree << log_n))) ||

@@ -278,11 +278,13 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
     }
 
 extern "C" int wf_fft_get_twiddles(wf_ctx *ctx, int field, uint32_t log_n, int inverse, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_out || log_n == 0) return WF_ERR_INVALID_ARG;
     WF_DISPATCH_FIELD(field, get_twiddles, ctx, log_n, inverse, d_out);
 }
 
 extern "C" int wf_fft_evaluate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_p, uint32_t log_n, uint32_t batch) {
+    WF_ENTER(ctx);
     if (!ctx || !d_p || batch == 0) return WF_ERR_INVALID_ARG;
     const uint64_t cs = (uint64_t)ext_degree << log_n;
     WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_p, log_n, batch, false, cs);
@@ -290,6 +292,7 @@ extern "C" int wf_fft_evaluate_poly(wf_ctx *ctx, int field, uint32_t ext_degree,
 
 extern "C" int wf_fft_interpolate_poly(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
                                        uint32_t batch) {
+    WF_ENTER(ctx);
     if (!ctx || !d_evals || batch == 0) return WF_ERR_INVALID_ARG;
     const uint64_t cs = (uint64_t)ext_degree << log_n;
     WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_evals, log_n, batch, true, cs);
@@ -297,12 +300,14 @@ extern "C" int wf_fft_interpolate_poly(wf_ctx *ctx, int field, uint32_t ext_degr
 
 extern "C" int wf_fft_evaluate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_p, uint32_t log_n,
                                                 const void *h_offset, uint32_t log_blowup, void *d_result) {
+    WF_ENTER(ctx);
     if (!ctx || !d_p || !d_result || log_n == 0) return WF_ERR_INVALID_ARG;
     WF_DISPATCH_FIELD(field, evaluate_with_offset, ctx, ext_degree, d_p, log_n, h_offset, log_blowup, d_result);
 }
 
 extern "C" int wf_fft_interpolate_poly_with_offset(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_evals, uint32_t log_n,
                                                    const void *h_offset) {
+    WF_ENTER(ctx);
     if (!ctx || !d_evals || log_n == 0) return WF_ERR_INVALID_ARG;
     WF_DISPATCH_FIELD(field, interpolate_with_offset, ctx, ext_degree, d_evals, log_n, h_offset);
 }
@@ -315,6 +320,7 @@ extern "C" uint64_t wf_row_width(uint32_t num_cols, uint32_t ext_degree) {
 
 extern "C" int wf_interpolate_columns(wf_ctx *ctx, int field, uint32_t ext_degree, void *d_cols, uint32_t num_cols,
                                       uint64_t col_stride, uint32_t log_n) {
+    WF_ENTER(ctx);
     if (!ctx || !d_cols || num_cols == 0) return WF_ERR_INVALID_ARG;
     if (col_stride < ((uint64_t)ext_degree << log_n)) return WF_ERR_INVALID_ARG;
     WF_DISPATCH_FIELD(field, fft_inplace_batch, ctx, ext_degree, d_cols, log_n, num_cols, true, col_stride);
@@ -331,6 +337,7 @@ int wf_evaluate_polys_over_fused(wf_ctx *ctx, int field, uint32_t ext_degree, co
 extern "C" int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
                                       uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset,
                                       void *d_lde) {
+    WF_ENTER(ctx);
     int fused;
     return wf_evaluate_polys_over_fused(ctx, field, ext_degree, d_polys, num_cols, col_stride, log_n, log_blowup, h_offset, d_lde, -1, nullptr,
                                         &fused);
@@ -339,6 +346,7 @@ extern "C" int wf_evaluate_polys_over(wf_ctx *ctx, int field, uint32_t ext_degre
 extern "C" int wf_evaluate_columns_over(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_polys, uint32_t num_cols,
                                         uint64_t col_stride, uint32_t log_n, uint32_t log_blowup, const void *h_offset, void *d_out,
                                         uint64_t out_col_stride) {
+    WF_ENTER(ctx);
     if (!ctx || !d_polys || !d_out || num_cols == 0 || log_n == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
     if (col_stride < ((uint64_t)ext_degree << log_n) || out_col_stride < ((uint64_t)ext_degree << (log_n + log_blowup)))
         return WF_ERR_INVALID_ARG;

@@ -219,12 +219,11 @@ int build_layers(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
     uint32_t k0 = num_layers;
     bool tail_remainder = false;
 #ifndef WF_NO_FRI_TAIL
-    if constexpr (sizeof(T) == 8) {
-        if (HF::Dev::ID == WF_FIELD_F64 && num_layers > 0 && (hash == WF_HASH_BLAKE3_256 || hash == WF_HASH_BLAKE3_192) && (D << log_nf) <= 16) {
-            uint32_t k = 0;
-            while (k < num_layers && log_len - (k + 1) * log_nf > 10) k++;    // FRI_TAIL_MAX_ROWS = 2^10 (fri_rows.hip)
-            if (k < num_layers && log_len - num_layers * log_nf >= 1) k0 = k;
-        }
+    {
+        uint32_t k = 0;
+        while (k < num_layers && log_len - (k + 1) * log_nf > 10) k++;        // the first layer of at most 2^10 rows
+        // wf_fri_tail_ok is the tail's own admission test: k0 is only moved when the launch WILL take the layers
+        if (k < num_layers && wf_fri_tail_ok(hash, HF::Dev::ID, D, log_nf, log_len - k * log_nf, num_layers - k)) k0 = k;
     }
 #endif
     const uint32_t log_len0 = log_len;
@@ -277,13 +276,13 @@ int build_layers(wf_ctx *ctx, int hash, uint32_t D, const void *d_evals, uint32_
                 n_inv = HF::to_internal(HF::invmod(HF::from_u64(rem_n)));
             }
             // in the tail: the remainder's hash is one chunk there (<= 1024 bytes); rem_n <= 1024 always holds (the tail's layers have <= 1024 rows)
-            const bool rem_in_tail = rem_size != 0 && (uint64_t)rem_size * D * 8 <= 1024 && rem_n <= 1024;
+            const bool rem_in_tail = rem_size != 0 && wf_fri_tail_rem_ok(D, log_rem, rem_size);
             int done = 0;
             WF_TRY(wf_fri_tail(ctx, hash, HF::Dev::ID, D, log_nf, k0 ? d_folded[k0 - 1] : d_evals, log_len, nt, d_transposed + k0, d_leaves + k0, d_nodes + k0,
                                d_folded + k0, (uint8_t *)d_roots + (size_t)k0 * 32, (uint8_t *)d_alphas + (size_t)k0 * D * sizeof(T), d_coin, io.d_lo, io.d_hi,
                                io.log_lo, w16, (uint64_t)inv_n, rem_in_tail ? d_remainder : nullptr, rem_size, (uint64_t)w_inv, (uint64_t)off_inv,
                                (uint64_t)n_inv, &done));
-            if (!done) return WF_ERR_UNSUPPORTED;      // k0 < num_layers was chosen for shapes the tail kernel covers
+            if (!done) return WF_ERR_UNSUPPORTED;      // cannot happen: k0 and rem_in_tail come from the tail's own predicates
             log_len -= nt * log_nf;
             tail_remainder = rem_in_tail;
         }
@@ -326,6 +325,7 @@ extern "C" int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ex
                                    uint32_t folding, uint32_t num_layers, const void *h_domain_offset, void *d_coin,
                                    void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded,
                                    void *d_roots, void *d_alphas, uint32_t blowup, void *d_remainder) {
+    WF_ENTER(ctx);
     if (!ctx || !d_evals || !h_domain_offset || !d_coin || !d_roots || (num_layers && !d_alphas)) return WF_ERR_INVALID_ARG;
     if (num_layers == 0 && !d_remainder) return WF_OK;
     if (num_layers && (!d_transposed || !d_leaves || !d_nodes || !d_folded)) return WF_ERR_INVALID_ARG;
@@ -343,6 +343,7 @@ extern "C" int wf_fri_build_layers(wf_ctx *ctx, int hash, int field, uint32_t ex
 extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals,
                                    uint32_t log_len, uint32_t folding, void *d_transposed, void *d_leaves, void *d_nodes,
                                    void *h_root) {
+    WF_ENTER(ctx);
     if (!ctx || !d_evals || !d_transposed || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
     switch (field) {
         case WF_FIELD_F64: return layer_commit<HostF64>(ctx, hash, ext_degree, d_evals, log_len, folding, d_transposed, d_leaves, d_nodes, h_root);
@@ -355,6 +356,7 @@ extern "C" int wf_fri_layer_commit(wf_ctx *ctx, int hash, int field, uint32_t ex
 extern "C" int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
                                      uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
                                      const void *h_alpha, void *d_folded) {
+    WF_ENTER(ctx);
     if (!ctx || !d_transposed_rows || !h_domain_offset || !h_alpha || !d_folded) return WF_ERR_INVALID_ARG;
     switch (field) {
         case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, h_alpha, nullptr, d_folded);
@@ -368,6 +370,7 @@ extern "C" int wf_fri_apply_drp_rows(wf_ctx *ctx, int field, uint32_t ext_degree
 extern "C" int wf_fri_apply_drp_rows_dev(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed_rows, uint32_t log_len,
                                          uint32_t folding, uint64_t row_start, uint64_t num_rows, const void *h_domain_offset,
                                          const void *d_alpha, void *d_folded) {
+    WF_ENTER(ctx);
     if (!ctx || !d_transposed_rows || !h_domain_offset || !d_alpha || !d_folded) return WF_ERR_INVALID_ARG;
     switch (field) {
         case WF_FIELD_F64: return apply_drp<HostF64>(ctx, ext_degree, d_transposed_rows, log_len, folding, row_start, num_rows, h_domain_offset, nullptr, d_alpha, d_folded);
@@ -379,6 +382,7 @@ extern "C" int wf_fri_apply_drp_rows_dev(wf_ctx *ctx, int field, uint32_t ext_de
 
 extern "C" int wf_fri_apply_drp(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_transposed, uint32_t log_len,
                                 uint32_t folding, const void *h_domain_offset, const void *h_alpha, void *d_folded) {
+    WF_ENTER(ctx);
     uint32_t log_nf = 0;
     while ((1u << log_nf) < folding && log_nf < 5) log_nf++;
     if (log_len < log_nf) return WF_ERR_INVALID_ARG;

@@ -458,6 +458,11 @@ __global__ __launch_bounds__(1024) void fri_tail_kernel(FriTailParams p) {
     }
 }
 
+// the (log2 folding factor, extension degree) pairs fri_tail_kernel is instantiated for: the WF_FT list below and nothing else
+constexpr bool fri_tail_has_kernel(uint32_t log_nf, uint32_t D) {
+    return (log_nf == 1 && D >= 1 && D <= 3) || (log_nf == 2 && D >= 1 && D <= 3) || (log_nf == 3 && (D == 1 || D == 2)) || (log_nf == 4 && D == 1);
+}
+
 template <class H>
 bool try_fri_tail(wf_ctx *ctx, uint32_t D, uint32_t log_nf, const FriTailParams &p) {
     if constexpr (!H::WAVE_TREE) {
@@ -517,21 +522,39 @@ int wf_fri_fold_commit(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, ui
 // elements); per layer k of the call d_transposed[k] / d_leaves[k] / d_nodes[k] / d_folded[k] as in wf_fri_build_layers; d_roots:
 // num_layers (+ 1 with a remainder) digests, d_alphas: num_layers elements; io_*: the series offset^-1 g^-i of layer 0 of the call.
 // *done = 0: not this shape, nothing was launched.
+// ONE predicate for "the tail launch covers these layers", used by wf_fri_tail itself and by build_layers (fri.hip) when it decides
+// BEFORE anything is queued which layers go to the tail (round-3 advice: two copies of these conditions that disagree would lose the
+// transcript — layers 0 .. k0-1 have reseeded the device coin by the time wf_fri_tail says no).  log_len = log2 of the evaluations
+// entering the first tail layer, nt = number of tail layers.
+int wf_fri_tail_ok(int hash, int field, uint32_t ext_degree, uint32_t log_nf, uint32_t log_len, uint32_t nt) {
+    if (field != WF_FIELD_F64 || nt == 0 || nt > (uint32_t)FRI_TAIL_MAX_LAYERS) return 0;
+    if (log_len < (uint64_t)nt * log_nf || log_len < log_nf + 1) return 0;
+    if ((1ull << (log_len - log_nf)) > FRI_TAIL_MAX_ROWS || ((ext_degree << log_nf) * 8) > 128) return 0;
+    if (log_len - nt * log_nf < 1) return 0;     // every layer needs at least two rows (MerkleTree::new: TooFewLeaves)
+    bool kernel = false;
+    const int st = with_hasher(hash, [&](auto h) {
+        kernel = decltype(h)::WAVE_TREE && fri_tail_has_kernel(log_nf, ext_degree);
+        return (int)WF_OK;
+    });
+    return st == WF_OK && kernel ? 1 : 0;
+}
+
+// ... and for "the remainder (rem_size coefficients out of 2^log_rem_n evaluations) is computed and hashed inside the tail launch"
+int wf_fri_tail_rem_ok(uint32_t ext_degree, uint32_t log_rem_n, uint32_t rem_size) {
+    if (rem_size == 0 || (rem_size & (rem_size - 1)) || rem_size > 1024 || log_rem_n > 10) return 0;
+    if ((uint64_t)rem_size * ext_degree * 8 > 1024) return 0;                       // its hash is one chunk in the kernel
+    return ((uint64_t)rem_size << log_rem_n) * ext_degree <= (1u << 17) ? 1 : 0;     // partial sums of one workgroup
+}
+
 int wf_fri_tail(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, uint32_t log_nf, const void *d_evals, uint32_t log_len, uint32_t num_layers,
                 void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded, void *d_roots, void *d_alphas, void *d_coin,
                 const void *io_lo, const void *io_hi, uint32_t io_log_lo, const void *w16, uint64_t inv_n, void *d_remainder, uint32_t rem_size,
                 uint64_t rem_w_inv, uint64_t rem_off_inv, uint64_t rem_n_inv, int *done) {
     *done = 0;
-    if (field != WF_FIELD_F64 || num_layers == 0 || num_layers > (uint32_t)FRI_TAIL_MAX_LAYERS) return WF_OK;
-    if (log_len < (uint64_t)num_layers * log_nf || log_len < log_nf + 1) return WF_OK;
+    if (!wf_fri_tail_ok(hash, field, ext_degree, log_nf, log_len, num_layers)) return WF_OK;
     const uint32_t log_rows0 = log_len - log_nf;
-    if ((1ull << log_rows0) > FRI_TAIL_MAX_ROWS || ((ext_degree << log_nf) * 8) > 128) return WF_OK;
-    // every layer needs at least two rows (MerkleTree::new: TooFewLeaves): the last one has 2^(log_len - num_layers log_nf) of them
-    if (log_len - num_layers * log_nf < 1) return WF_OK;
     const uint32_t log_rem_n = log_len - num_layers * log_nf;
-    if (d_remainder) {
-        if (rem_size == 0 || (rem_size & (rem_size - 1)) || rem_size > 1024 || ((uint64_t)rem_size << log_rem_n) * ext_degree > (1u << 17)) return WF_OK;
-    }
+    if (d_remainder && !wf_fri_tail_rem_ok(ext_degree, log_rem_n, rem_size)) return WF_OK;
     FriTailParams p{};
     p.ev = (const uint64_t *)d_evals;
     p.log_rows0 = log_rows0;

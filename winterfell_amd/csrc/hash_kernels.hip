@@ -434,6 +434,7 @@ int wf_lde_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree,
 }
 
 extern "C" int wf_hash_merge_batch(wf_ctx *ctx, int hash, const void *d_pairs, uint64_t count, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_pairs || !d_out) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (count == 0) return WF_OK;
@@ -524,6 +525,7 @@ static int hash_rows_impl(wf_ctx *ctx, int hash, int field, uint32_t D, const vo
 extern "C" int wf_hash_rows(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_rows, uint64_t num_rows,
                             uint64_t row_width, uint32_t elems_per_row, uint32_t num_partitions, uint32_t hash_rate,
                             void *d_leaves) {
+    WF_ENTER(ctx);
     return hash_rows_impl(ctx, hash, field, ext_degree, d_rows, num_rows, row_width, elems_per_row, num_partitions,
                           hash_rate, d_leaves);
 }
@@ -541,6 +543,7 @@ __global__ __launch_bounds__(256) void hash_bytes_kernel(const uint64_t *msgs, u
 
 extern "C" int wf_hash_bytes_batch(wf_ctx *ctx, int hash, const void *d_msgs, uint64_t count, uint64_t stride_bytes, uint64_t len_bytes,
                                    void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_out || (count && len_bytes && !d_msgs)) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (hash != WF_HASH_BLAKE3_256 && hash != WF_HASH_BLAKE3_192 && hash != WF_HASH_SHA3_256) return WF_ERR_UNSUPPORTED;
@@ -559,6 +562,7 @@ extern "C" int wf_hash_bytes_batch(wf_ctx *ctx, int hash, const void *d_msgs, ui
 
 extern "C" int wf_hash_columns(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_cols, uint32_t num_cols,
                                uint64_t col_stride, uint64_t num_rows, void *d_leaves) {
+    WF_ENTER(ctx);
     if (!ctx || !d_cols || !d_leaves || num_cols == 0 || num_rows == 0 || ext_degree == 0) return WF_ERR_INVALID_ARG;
     if (col_stride < num_rows * ext_degree) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
@@ -584,11 +588,13 @@ extern "C" int wf_hash_columns(wf_ctx *ctx, int hash, int field, uint32_t ext_de
 
 extern "C" int wf_hash_elements_batch(wf_ctx *ctx, int hash, int field, const void *d_elems, uint64_t count,
                                       uint64_t row_width, uint32_t elems_per_row, void *d_out) {
+    WF_ENTER(ctx);
     if (count == 0) return WF_OK;
     return hash_rows_impl(ctx, hash, field, 1, d_elems, count, row_width, elems_per_row, 1, 1, d_out);
 }
 
 extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_digests, uint64_t count, uint32_t k, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_digests || !d_out || k == 0) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (count == 0) return WF_OK;
@@ -601,6 +607,7 @@ extern "C" int wf_hash_merge_many_batch(wf_ctx *ctx, int hash, const void *d_dig
 
 extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h_seed, uint64_t first_value, uint64_t count,
                                            void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !h_seed || !d_out) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (count == 0) return WF_OK;
@@ -629,6 +636,7 @@ extern "C" int wf_hash_merge_with_int_batch(wf_ctx *ctx, int hash, const void *h
 
 extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grinding_factor, uint64_t first_nonce,
                         uint64_t max_nonce, uint64_t *h_nonce) {
+    WF_ENTER(ctx);
     if (!ctx || !h_seed || !h_nonce || grinding_factor > 64 || first_nonce > max_nonce) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     Seed seed;
@@ -658,8 +666,7 @@ extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grin
         }));
         WF_HIP(hipGetLastError());
         unsigned long long best;
-        WF_HIP(hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, ctx->stream));
-        WF_HIP(hipStreamSynchronize(ctx->stream));
+        WF_TRY(wf_copy_d2h(ctx, &best, d_best, 8));
         if (best != ~0ull) {
             *h_nonce = best;
             return WF_OK;
@@ -671,6 +678,7 @@ extern "C" int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grin
 
 extern "C" int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width, uint32_t elems_per_row,
                              uint32_t elem_bytes, const uint64_t *h_positions, uint32_t count, void *h_out) {
+    WF_ENTER(ctx);
     if (!ctx || !d_rows || !h_positions || !h_out || (elem_bytes != 8 && elem_bytes != 16)) return WF_ERR_INVALID_ARG;
     if (count == 0) return WF_OK;
     const uint64_t row_bytes = row_width * elem_bytes;
@@ -679,20 +687,20 @@ extern "C" int wf_rows_fetch(wf_ctx *ctx, const void *d_rows, uint64_t row_width
     WF_TRY(wf_scratch(ctx, 2, (size_t)count * (take + 8), &tmp));
     uint64_t *d_pos = (uint64_t *)tmp;
     uint8_t *d_out = (uint8_t *)tmp + (size_t)count * 8;
-    WF_HIP(hipMemcpyAsync(d_pos, h_positions, (size_t)count * 8, hipMemcpyHostToDevice, ctx->stream));
+    WF_TRY(wf_copy_h2d(ctx, d_pos, h_positions, (size_t)count * 8));
     const uint64_t total = (uint64_t)count * (take / 8);
     hipLaunchKernelGGL(gather_rows_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, ctx->stream,
                        (const uint8_t *)d_rows, row_bytes, take, d_pos, count, d_out);
     WF_HIP(hipGetLastError());
-    WF_HIP(hipMemcpyAsync(h_out, d_out, (size_t)count * take, hipMemcpyDeviceToHost, ctx->stream));
-    WF_HIP(hipStreamSynchronize(ctx->stream));
-    return WF_OK;
+    WF_TRY(wf_copy_d2h(ctx, h_out, d_out, (size_t)count * take));
+    return wf_check_status(ctx);
 }
 
 extern "C" int wf_build_trace_commitment(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_trace,
                                          uint32_t num_cols, uint64_t col_stride, uint32_t log_n, uint32_t log_blowup,
                                          const void *h_offset, uint32_t num_partitions, uint32_t hash_rate,
                                          int skip_interpolate, void *d_lde, void *d_leaves, void *d_nodes, void *h_root) {
+    WF_ENTER(ctx);
     if (!ctx || !d_trace || !d_lde || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (ext_degree == 0 || num_cols == 0 || num_partitions < 1 || num_partitions > 16 || hash_rate < 1 || hash_rate > 256) return WF_ERR_INVALID_ARG;

@@ -122,12 +122,14 @@ int batch_inversion(wf_ctx *ctx, const void *d_values, uint64_t n, void *d_out) 
     }
 
 extern "C" int wf_get_power_series_with_offset(wf_ctx *ctx, int field, const void *h_b, const void *h_s, uint64_t n, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || !h_b || !h_s || (n && !d_out)) return WF_ERR_INVALID_ARG;
     if (n == 0) return WF_OK;
     WF_DISPATCH_FIELD(field, power_series, ctx, h_b, h_s, n, d_out);
 }
 
 extern "C" int wf_batch_inversion(wf_ctx *ctx, int field, const void *d_values, uint64_t n, void *d_out) {
+    WF_ENTER(ctx);
     if (!ctx || (n && (!d_values || !d_out))) return WF_ERR_INVALID_ARG;
     if (n == 0) return WF_OK;
     WF_DISPATCH_FIELD(field, batch_inversion, ctx, d_values, n, d_out);

@@ -47,8 +47,8 @@ __global__ __launch_bounds__(THREADS) void merkle_stage_coin_kernel(const void *
 // LOG_IN = 12: 4096 inputs per workgroup (trees of 2^19 and 2^20 inputs in one launch as well): the two levels below the stage go
 // global to global, two and one merges per lane, and the workgroup reads its own 1024 outputs back (same CU, behind a barrier).
 template <class H, int FIELD, int D, bool COIN, int LOG_IN = 10>
-__global__ __launch_bounds__(1024) void merkle_finish_kernel(const void *in, void *nodes, uint64_t count, uint32_t *ticket, CoinState *coin,
-                                                             uint32_t *root_out, uint64_t *alpha_out) {
+__global__ __launch_bounds__(1024) void merkle_finish_kernel(const void *in, void *nodes, uint64_t count, uint32_t *ticket, uint32_t epoch,
+                                                             uint32_t *status, CoinState *coin, uint32_t *root_out, uint64_t *alpha_out) {
     __shared__ uint4 bufA[512 * 2];
     __shared__ uint4 bufB[256 * 2];
     __shared__ uint32_t s_last;
@@ -81,12 +81,24 @@ __global__ __launch_bounds__(1024) void merkle_finish_kernel(const void *in, voi
         // a device-scope release writes the XCD's L2 back, and 16 wavefronts x 256 workgroups doing it cost 30 us a tree
         __syncthreads();
         if (tid == 0) {
-            __threadfence();
-            s_last = atomicAdd(ticket, 1u) == wgs - 1 ? 1u : 0u;
-            if (s_last) {
-                atomicExch(ticket, 0u);
-                __threadfence();
+            // release: the XCD's L2 is written back; the explicit wait keeps the ticket from overtaking the write-back (the compiler drops
+            // the wait after buffer_wbl2 when it can prove the wave's memory counter empty, MI355X_MICROARCH.md "Compiler hazard")
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // the ticket word carries the epoch of its use in the high 12 bits: a word that is not in the state this launch expects — never
+            // zeroed, shared with another tree in flight, written by something else — is REPORTED (the context's status word, checked by the
+            // next synchronising call) instead of silently leaving the top of the tree unwritten
+            const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t seen = old & 0xfffffu;
+            uint32_t last = 0;
+            if ((old >> 20) != epoch || seen >= wgs) {
+                __hip_atomic_fetch_or(status, WF_STATUS_MERKLE_TICKET, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else if (seen == wgs - 1) {
+                last = 1;
+                __hip_atomic_store(ticket, ((epoch + 1) & 0xfffu) << 20, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // this CU's L1 forgets what it held of the other subtrees
             }
+            s_last = last;
         }
         __syncthreads();
         if (!s_last) return;
@@ -303,27 +315,23 @@ int launch_finish(wf_ctx *ctx, const void *in, void *nodes, uint64_t count, Coin
     if constexpr (!H::QUAD_MERGE) {
         return WF_OK;
     } else {
-        if (!ctx->d_tree_ticket) {
-            // once per context.  The zeroing is waited for: hipMemset on device memory does not block the host, and the launch below may
-            // sit on a non-blocking stream that the null stream does not order (a fresh context on a torch side stream read garbage
-            // tickets: tools/stress_contexts.py), while a later wf_ctx_set_stream must not find the fill still queued on the old stream
-            WF_HIP(hipMalloc(&ctx->d_tree_ticket, WF_TREE_TICKETS * sizeof(uint32_t)));
-            ctx->owned.push_back(ctx->d_tree_ticket);
-            WF_HIP(hipMemsetAsync(ctx->d_tree_ticket, 0, WF_TREE_TICKETS * sizeof(uint32_t), ctx->stream));
-            WF_HIP(hipStreamSynchronize(ctx->stream));
-        }
+        // the ticket ring was allocated and zeroed by wf_ctx_create (no allocation, no synchronisation on the launch path)
         const bool big = count > (1u << 18);                       // 2^19, 2^20 inputs: 4096 per workgroup
         const dim3 grid((uint32_t)(count >> (big ? 12 : 10)));
         // a ring of ticket words: a caller that moves the context to another stream (wf_ctx_set_stream) may have two trees in flight
-        uint32_t *tk = (uint32_t *)ctx->d_tree_ticket + (ctx->tree_ticket_next++ % WF_TREE_TICKETS);
+        const uint32_t slot = ctx->tree_ticket_next++ % WF_TREE_TICKETS;
+        uint32_t *tk = (uint32_t *)ctx->d_tree_ticket + slot;
+        const uint32_t ep = ctx->tree_ticket_epoch[slot];
+        ctx->tree_ticket_epoch[slot] = (ep + 1) & 0xfffu;
+        uint32_t *st = ctx->d_status;
         if (ct) {
             CoinState *c = (CoinState *)ct->coin;
             uint32_t *ro = (uint32_t *)ct->root_out;
             uint64_t *ao = (uint64_t *)ct->alpha_out;
 #define WF_MF(F, DD)                                                                                                                                        \
     if (ct->field == F && ct->D == DD) {                                                                                                                    \
-        if (big) hipLaunchKernelGGL((merkle_finish_kernel<H, F, DD, true, 12>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, c, ro, ao);          \
-        else hipLaunchKernelGGL((merkle_finish_kernel<H, F, DD, true, 10>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, c, ro, ao);              \
+        if (big) hipLaunchKernelGGL((merkle_finish_kernel<H, F, DD, true, 12>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, ep, st, c, ro, ao);  \
+        else hipLaunchKernelGGL((merkle_finish_kernel<H, F, DD, true, 10>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, ep, st, c, ro, ao);      \
         ct->done = true;                                                                                                                                    \
         *launched = true;                                                                                                                                   \
         return WF_OK;                                                                                                                                       \
@@ -332,10 +340,10 @@ int launch_finish(wf_ctx *ctx, const void *in, void *nodes, uint64_t count, Coin
 #undef WF_MF
         }
         if (big)
-            hipLaunchKernelGGL((merkle_finish_kernel<H, WF_FIELD_F64, 1, false, 12>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk,
+            hipLaunchKernelGGL((merkle_finish_kernel<H, WF_FIELD_F64, 1, false, 12>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, ep, st,
                                (CoinState *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
         else
-            hipLaunchKernelGGL((merkle_finish_kernel<H, WF_FIELD_F64, 1, false, 10>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk,
+            hipLaunchKernelGGL((merkle_finish_kernel<H, WF_FIELD_F64, 1, false, 10>), grid, dim3(1024), 0, ctx->stream, in, nodes, count, tk, ep, st,
                                (CoinState *)nullptr, (uint32_t *)nullptr, (uint64_t *)nullptr);
         *launched = true;
         return WF_OK;
@@ -460,6 +468,7 @@ int launch_merkle(wf_ctx *ctx, const void *leaves, uint64_t num_leaves, void *no
 }  // namespace
 
 extern "C" int wf_merkle_build(wf_ctx *ctx, int hash, const void *d_leaves, uint64_t num_leaves, void *d_nodes) {
+    WF_ENTER(ctx);
     if (!ctx || !d_leaves || !d_nodes) return WF_ERR_INVALID_ARG;
     WF_TRY(check_hash(hash));
     if (num_leaves < 2) return WF_ERR_TOO_FEW_LEAVES;

@@ -692,7 +692,7 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
     auto it = ctx->pass_twiddles.find(key);
     if (it == ctx->pass_twiddles.end()) {
         void *d;
-        WF_HIP(hipMalloc(&d, (sizeof(T) * (F::USE_L24 ? 4 : 1)) << log_total));
+        WF_TRY(wf_dev_malloc(ctx, &d, (sizeof(T) * (F::USE_L24 ? 4 : 1)) << log_total));
         ctx->owned.push_back(d);
         const uint32_t total = 1u << log_total;
         hipLaunchKernelGGL(pass_twiddle_table_kernel<F>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, (const T *)om.d_lo, (const T *)om.d_hi,

@@ -14,10 +14,9 @@ static inline void split128(T v, uint64_t &lo, uint64_t &hi) {
 template <class T>
 static int wf_upload(wf_ctx *ctx, const std::vector<T> &h, void **d) {
     void *p;
-    WF_HIP(hipMalloc(&p, h.size() * sizeof(T)));
+    WF_TRY(wf_dev_malloc(ctx, &p, h.size() * sizeof(T)));
     ctx->owned.push_back(p);
-    WF_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
-    WF_HIP(hipStreamSynchronize(ctx->stream));  // h goes out of scope in the caller
+    WF_TRY(wf_copy_h2d(ctx, p, h.data(), h.size() * sizeof(T)));   // synchronises: h goes out of scope in the caller
     *d = p;
     return WF_OK;
 }

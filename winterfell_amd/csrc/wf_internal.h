@@ -2,8 +2,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <tuple>
 #include <vector>
@@ -38,11 +40,17 @@ struct SeriesTable {
 typedef std::tuple<int, uint64_t, uint64_t, uint64_t, uint64_t, uint32_t> SeriesKey;   // field, base, scale (128-bit each), log_len
 
 #define WF_TREE_TICKETS 64
+#define WF_STATUS_MERKLE_TICKET 1u    // bit of the device status word: a Merkle ticket word was not in the expected state
 struct wf_ctx {
+    // Every extern "C" entry point holds this for its whole duration (WF_ENTER): calls on ONE context from several host threads are
+    // serialised instead of racing on the caches below (std::map, pool, scratch, ticket ring).  The reference's TraceLde is Sync and is
+    // read from Rayon workers (prover/src/constraints/evaluator/default.rs:187); one context per thread stays the FAST way to call.
+    std::recursive_mutex mu;
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
     int last_hip_error = 0;
+    uint32_t last_device_status = 0;
 
     // geometric-series tables (twiddles omega_n^i, coset offsets, FRI inverse offsets), keyed by SeriesKey
     std::map<SeriesKey, SeriesTable> series;
@@ -90,8 +98,17 @@ struct wf_ctx {
     // WF_NTT_PLAN, parsed once at context creation (context.hip): a pass plan for transforms of 2^plan_log_n points, 0 = none
     uint32_t plan_log_n = 0, plan_npass = 0, plan_log_r[6] = {0, 0, 0, 0, 0, 0};
 
+    // pinned bounce buffers for host <-> device copies of PAGEABLE caller memory (context.hip: staged_copy)
+    void *h_bounce[2] = {nullptr, nullptr};
+    hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    // device status word (one uint32_t, zero = fine): kernels that detect a protocol failure (a Merkle ticket that can never
+    // complete) set a bit; wf_ctx_sync and every synchronising entry point report it as WF_ERR_DEVICE_STATUS
+    uint32_t *d_status = nullptr;
+    uint32_t *h_status = nullptr;     // pinned mirror
+
     void *d_tree_ticket = nullptr;     // merkle_finish_kernel's ticket words (WF_TREE_TICKETS of them, each zero between its launches)
     uint32_t tree_ticket_next = 0;
+    uint32_t tree_ticket_epoch[WF_TREE_TICKETS] = {};   // the epoch each ticket word carries in its high 12 bits (merkle_finish_kernel)
 
     // scratch buffers (grow-only)
     void *scratch[3] = {nullptr, nullptr, nullptr};
@@ -100,6 +117,36 @@ struct wf_ctx {
 };
 
 int wf_scratch(wf_ctx *ctx, int slot, size_t bytes, void **out);
+// All device allocations of the library go through these two (context.hip).  WF_DEBUG_GUARD=1 (read once per process) turns every
+// allocation into its own virtual-address reservation with unmapped pages on both sides and the block's END on the last mapped byte,
+// so that a kernel that reads or writes past a buffer faults at once instead of landing in a neighbour (tests/README_guard.md);
+// WF_DEBUG_GUARD=2 keeps hipMalloc and surrounds every block with red zones that are checked when it is freed.
+int wf_dev_malloc(wf_ctx *ctx, void **d_ptr, size_t bytes);
+int wf_dev_free(wf_ctx *ctx, void *d_ptr);
+// host <-> device copies that never hand PAGEABLE caller memory to the runtime (see context.hip); synchronise the stream
+int wf_copy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
+int wf_copy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+int wf_check_status(wf_ctx *ctx);    // after a stream synchronisation: WF_ERR_DEVICE_STATUS when a kernel flagged a failure
+
+// several small host -> device copies whose destinations lie in ONE device block: collected into a host image, flushed as one
+// staged copy (one stream synchronisation instead of one per piece); gaps between the pieces are written as zeros
+struct WfUploadBatch {
+    wf_ctx *ctx;
+    char *d_base;
+    std::vector<char> image;
+    WfUploadBatch(wf_ctx *c, void *base) : ctx(c), d_base((char *)base) {}
+    void add(void *d_dst, const void *h_src, size_t n) {
+        if (n == 0) return;
+        const size_t off = (size_t)((char *)d_dst - d_base);
+        if (image.size() < off + n) image.resize(off + n);
+        memcpy(&image[off], h_src, n);
+    }
+    int flush() { return image.empty() ? (int)WF_OK : wf_copy_h2d(ctx, d_base, image.data(), image.size()); }
+};
+
+#define WF_ENTER(ctx)                                   \
+    if (!(ctx)) return WF_ERR_INVALID_ARG;              \
+    std::lock_guard<std::recursive_mutex> wf_lock_((ctx)->mu)
 int wf_resident_blocks(wf_ctx *ctx, const void *kernel, uint32_t *out);   // 256-thread workgroups resident on the whole device
 
 // RAII-less helpers: bracket a kernel launch with events when profiling is on
@@ -183,6 +230,8 @@ int wf_fri_tail(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, uint32_t 
                 void *const *d_transposed, void *const *d_leaves, void *const *d_nodes, void *const *d_folded, void *d_roots, void *d_alphas, void *d_coin,
                 const void *io_lo, const void *io_hi, uint32_t io_log_lo, const void *w16, uint64_t inv_n, void *d_remainder, uint32_t rem_size,
                 uint64_t rem_w_inv, uint64_t rem_off_inv, uint64_t rem_n_inv, int *done);   // fri_rows.hip
+int wf_fri_tail_ok(int hash, int field, uint32_t ext_degree, uint32_t log_nf, uint32_t log_len, uint32_t nt);   // fri_rows.hip
+int wf_fri_tail_rem_ok(uint32_t ext_degree, uint32_t log_rem_n, uint32_t rem_size);
 int wf_fri_transpose_hash(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, const void *d_evals, uint32_t log_rc, uint32_t log_nf,
                           void *d_transposed, void *d_leaves, int *done);   // hash_kernels.hip
 int wf_ntt_run(wf_ctx *ctx, const NttJob &job);          // dispatches on job.field
