@@ -295,7 +295,8 @@ enum {
  * transition constraints, merge them with h_cc_transition, divide by the transition divisor
  * (x^n - 1) / (x - g^(n-1)) (air/src/air/divisor.rs:43-51), add every boundary group
  * sum_a cc_a (state[col_a] - value_a) / (x - g^step_a) (evaluator/boundary.rs:213-232,318-327; divisor.rs:55-71).
- * Assertions are single-value (Assertion::single): columns / steps / values (base field, internal form) / coefficients
+ * Assertions here are single-value (Assertion::single; periodic and sequence assertions: wf_evaluate_constraints_assertions below):
+ * columns / steps / values (base field, internal form) / coefficients
  * (ext_degree words each) in any order — the result does not depend on it.  log_ce_blowup must be the AIR's
  * ce_blowup_factor (FibSmall 2, Rescue 4; air/src/air/context.rs:104-117), log_lde_blowup >= log_ce_blowup.
  * d_out: 2^(log_n + log_ce_blowup) elements of ext_degree words = CompositionPolyTrace, the input of
@@ -305,6 +306,23 @@ int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree
                             const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
                             const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
                             void *d_out);
+
+/* The same with assertions of every kind (air/src/air/assertions/mod.rs:57-120) against the main segment: assertion k is
+ * (column, first_step, stride, num_values) with its values back to back in h_assert_values —
+ *   stride 0, one value:                       Assertion::single   (the entry point above)
+ *   stride 2^j >= 2, first_step < stride, one value:            Assertion::periodic (the value at first_step + i stride for every i)
+ *   the same with trace_length / stride values:                 Assertion::sequence (values[i] at first_step + i stride).
+ * The boundary constraint is f(x) - b(x) over the divisor x^k - g^(first_step k), k = the number of asserted steps
+ * (air/src/air/divisor.rs:64-97); b is the value, or for a sequence the polynomial interpolated from the values and evaluated at
+ * x g^(-first_step) (air/src/air/boundary/constraint.rs:60-147) — an inverse transform of the values and one coset evaluation over the
+ * constraint-evaluation domain per sequence, on the device.  Groups are keyed by (stride, first_step) (boundary/mod.rs:168-186); at most 8
+ * groups and 64 assertions.  WF_ERR_INVALID_ARG for a stride / first step / value count the reference's constructors reject. */
+int wf_evaluate_constraints_assertions(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                       uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                       const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                       const uint64_t *h_assert_first_steps, const uint64_t *h_assert_strides,
+                                       const uint64_t *h_assert_num_values, const void *h_assert_values, const void *h_cc_boundary,
+                                       void *d_out);
 
 /* The same for a trace with an auxiliary segment (TraceInfo::is_multi_segment): evaluate_fragment_full
  * (evaluator/default.rs:214-271) = the main transition constraints as above plus Air::evaluate_aux_transition over the

@@ -668,6 +668,27 @@ class GenericField:
         assert rc == 0
         return out
 
+    def evaluate_constraints_multi(self, air, lde, row_width, n, lde_blowup, ce_blowup, offset, D, cc_t, assertions, cc_b):
+        """the same with assertions of every kind (air/src/air/assertions/mod.rs:57-120): a list of (column, first_step, stride, value
+        words) — stride 0 = Assertion::single (one value), stride > 0 with ONE value = Assertion::periodic, with trace_length / stride
+        values = Assertion::sequence.  cc_b: one coefficient (D elements) per assertion, in the list's order."""
+        l, t, b = _u64arr(lde), _u64arr(cc_t), _u64arr(cc_b)
+        cols = np.array([a[0] for a in assertions], dtype=np.uint64)
+        first = np.array([a[1] for a in assertions], dtype=np.uint64)
+        stride = np.array([a[2] for a in assertions], dtype=np.uint64)
+        vl = [_u64arr(a[3]).reshape(-1) for a in assertions]
+        nvals = np.array([len(v) // self.W for v in vl], dtype=np.uint64)
+        voff = np.concatenate([[0], np.cumsum(nvals)[:-1]]).astype(np.uint64)
+        vals = np.concatenate(vl)
+        po = self.pack([offset])
+        out = np.empty(n * ce_blowup * D * self.W, dtype=np.uint64)
+        fn = self._fn("evaluate_constraints_multi")
+        fn.restype = ctypes.c_int
+        rc = fn(ctypes.c_int(air), _ptr(l), _u64(row_width), _u64(n), _u64(lde_blowup), _u64(ce_blowup), _ptr(po), ctypes.c_uint(D),
+                _ptr(t), _u64(len(assertions)), _ptr(cols), _ptr(first), _ptr(stride), _ptr(nvals), _ptr(voff), _ptr(vals), _ptr(b), _ptr(out))
+        assert rc == 0, rc
+        return out
+
     def evaluate_constraints_full(self, air, lde, row_width, aux_lde, aux_row_width, n, lde_blowup, ce_blowup, offset, D, cc_t, assertions,
                                   cc_b, aux_assertions, cc_x, rand):
         """the same for a trace with an auxiliary segment (evaluate_fragment_full): aux_lde (n*lde_blowup, aux_row_width*W) words,

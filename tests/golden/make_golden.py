@@ -148,6 +148,13 @@ def main():
         {"a": v[i:i + 3], "b": v[i + 3:i + 6], "out": v[i + 6:i + 9]} for i in range(0, 27, 9)]
     vec["reference"]["f64_edge"] = {                                   # f64/tests.rs:64-73 (mul edge cases)
         "m_minus_1_squared": 1, "m_minus_1_times_2": M - 2, "half_times_2": 1}
+    # f62 cubic extension products (math/src/field/f62/tests.rs:128-187): within bounds and two cases "with overflow"
+    f62src = (REF / "math/src/field/f62/tests.rs").read_text()
+    m = re.search(r"fn cube_mul\(\)(.*?)\n}\n", f62src, re.S)
+    v = new_vals(m.group(1))
+    assert len(v) == 27 and v[:3] == [15, 22, 8] and v[6] == 4611624995532046021
+    vec["reference"]["f62_cube_mul"] = [
+        {"a": v[i:i + 3], "b": v[i + 3:i + 6], "out": v[i + 6:i + 9]} for i in range(0, 27, 9)]
     # trace-LDE fixture: prover/src/tests/mod.rs:19-31 build_fib_trace(16) and
     # prover/src/trace/trace_lde/default/tests.rs:22-106 expected polynomial evaluations
     vec["reference"]["fib_trace_col0"] = [1, 2, 5, 13, 34, 89, 233, 610]

@@ -77,6 +77,39 @@ def test_evaluate_constraints_vs_oracle(wf, oracle, fname, air_id, n, D, blowup)
     assert np.array_equal(ctx.to_host(out), want)
 
 
+@pytest.mark.parametrize("fname,air_id,n,D,blowup", [("f64", 0, 64, 2, 8), ("f128", 0, 256, 1, 8), ("f62", 0, 64, 3, 4), ("f128", 1, 128, 2, 8),
+                                                     ("f64", 4, 1 << 14, 2, 4)])
+def test_periodic_and_sequence_assertions_vs_oracle(wf, oracle, fname, air_id, n, D, blowup):
+    """Assertion::periodic / Assertion::sequence (air/src/air/assertions/mod.rs:84-120) in the device evaluator
+    (wf_evaluate_constraints_assertions): an AIR whose get_assertions mixes single, periodic and sequence assertions over several
+    (stride, first_step) groups — strides down to 2 (n / 2 asserted steps) and sequences of up to n / 4 values — against the oracle's
+    evaluator, which tests/test_oracle_constraints.py pins to the reference's definition with python integers."""
+    ctx, prover, fields, air_mod, crypto = wf
+    fld, ofld, trace, air = _setup(oracle, fields, air_mod, fname, air_id, n, blowup)
+    cols = [fld.unpack(trace[c]) for c in range(2)]
+    A = air_mod.Assertion
+    extra = [A.periodic(1, 3, 16, fld.new(123456789)), A.periodic(0, 1, 2, fld.new(5)),
+             A.sequence(1, 1, 8, [cols[1][1 + 8 * j] for j in range(n // 8)]), A.sequence(0, 0, 4, [cols[0][4 * j] for j in range(n // 4)]),
+             A.sequence(0, 1, 8, [cols[0][1 + 8 * j] for j in range(n // 8)]), A.sequence(1, 0, n, [cols[1][0]])]      # the last one is a single assertion
+    base = air.get_assertions()
+    air.get_assertions = lambda: base + extra
+    air._num_main_assertions = air._num_assertions = len(base) + len(extra)
+    out, cc, ev, lde, polys, domain = _gpu_eval(ctx, prover, crypto, fld, trace, air, D, blowup, 3 * n + D)
+    assert [a.stride for a in ev.assertions] == sorted(a.stride for a in ev.assertions) and any(a.is_sequence() for a in ev.assertions)
+    o_lde = ofld.build_trace_commitment(0, trace, blowup, int(domain.offset))[1]
+    want = ofld.evaluate_constraints_multi(air.AIR_ID, o_lde, o_lde.shape[1] // fld.W, n, blowup, air.ce_blowup_factor(), int(domain.offset), D,
+                                           cc.transition.reshape(-1), [(a.column, a.first_step, a.stride, fld.pack(a.values)) for a in ev.assertions],
+                                           cc.boundary.reshape(-1))
+    assert np.array_equal(ctx.to_host(out), want)
+    # what the reference's constructors reject is an argument error here as well
+    from winterfell_amd._lib import WfError
+    for bad in (A(0, 0, fld.new(1), stride=3), A(0, 4, fld.new(1), stride=4), A(0, 0, fld.new(1), stride=4, values=[fld.new(1)] * 3),
+                A(0, 0, fld.new(1), stride=2 * n)):
+        ev.assertions[-1] = bad
+        with pytest.raises((WfError, AssertionError)):
+            ev.evaluate(lde, domain)
+
+
 def test_argument_checks(wf, oracle):
     ctx, prover, fields, air_mod, crypto = wf
     from winterfell_amd._lib import WfError

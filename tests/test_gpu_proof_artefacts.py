@@ -94,6 +94,7 @@ def _check(want, proof, fld):
 
 
 @pytest.mark.parametrize("example,fname,hname,n,D", [("fib_small", "f64", "Blake3_256", 1 << 10, 1), ("fib_small", "f64", "Rp64_256", 1 << 8, 2),
+                                                      ("fib_small", "f64", "Blake3_256", 1 << 16, 1),      # BASELINE configs[0] at its stated size: 2^16 rows, blowup 8, Blake3_256
                                                       ("fib_small", "f64", "Blake3_256", 1 << 12, 3), ("rescue", "f128", "Blake3_256", 1 << 10, 2),
                                                       ("rescue", "f128", "Blake3_256", 1 << 10, 1),
                                                       ("rescue_raps", "f128", "Blake3_256", 1 << 9, 2), ("rescue_raps", "f128", "Blake3_256", 1 << 10, 1)])

@@ -45,6 +45,7 @@ def _gpu_proof(oracle, example, hname, n, D, num_queries=28, blowup=8, grinding=
 
 
 @pytest.mark.parametrize("example,hname,n,D", [("fib_small", "Blake3_256", 1 << 10, 1), ("fib_small", "Blake3_256", 1 << 12, 2), ("fib_small", "Blake3_256", 1 << 8, 3),
+                                               ("fib_small", "Blake3_256", 1 << 16, 1),      # BASELINE configs[0] at its stated size
                                                ("fib_small", "Rp64_256", 1 << 8, 1), ("fib_small", "Rp64_256", 1 << 9, 2), ("fib_small", "Rp64_256", 1 << 8, 3),
                                                ("rescue", "Blake3_256", 1 << 10, 2), ("rescue", "Blake3_256", 1 << 10, 1),
                                                ("rescue_raps", "Blake3_256", 1 << 9, 2), ("rescue_raps", "Blake3_256", 1 << 12, 1)])

@@ -207,3 +207,74 @@ def test_aux_segment_invalid_trace_breaks_divisibility(oracle, where):
     c = _raps_case(oracle, 64, 2, 4, corrupt=where)
     co = _composition_coeffs(c)
     assert co[c["ncols"] * 64:].any()
+
+
+def _value_poly(vals, M, wk):
+    """coefficients of the polynomial with b(wk^j) = vals[j] (the inverse DFT, written out with python integers)"""
+    k = len(vals)
+    kinv = pow(k, M - 2, M)
+    return [kinv * sum(v * pow(wk, (-j * m) % k, M) for j, v in enumerate(vals)) % M for m in range(k)]
+
+
+@pytest.mark.parametrize("fname", ["f128", "f64"])
+def test_multi_value_assertions_follow_the_reference_definition(oracle, fname):
+    """Assertion::periodic and Assertion::sequence (air/src/air/assertions/mod.rs:84-120) in the restated evaluator, against the
+    reference's definition written out with python integers: the boundary constraint of an assertion is f(x) - b(x) over the divisor
+    x^k - g^(first_step k), k = the number of asserted steps (air/src/air/divisor.rs:64-97); b is the value, or for a sequence the
+    polynomial interpolated from the values and evaluated at x g^(-first_step) (air/src/air/boundary/constraint.rs:60-147).  With the
+    transition coefficients zeroed, every point of the constraint-evaluation domain must equal the sum of the groups' quotients."""
+    fld, offset, new = _setup(oracle, fname)
+    W, M, n, lde_blowup, ce_blowup = fld.W, fld.M, 64, 8, 2
+    canon = (lambda v: int(oracle.f64_as_int(v))) if fname == "f64" else int
+    trace = fld.fib_small_build_trace(n)
+    cols = [[canon(v) for v in fld.unpack(trace[c])] for c in range(2)]
+    polys, lde, _, _ = fld.build_trace_commitment(0, trace, lde_blowup, offset)
+    # (column, first_step, stride, canonical values): single, periodic (not true of this trace: the evaluator does not care), two sequences
+    A = [(0, 0, 0, [1]), (1, 3, 16, [123456789]), (1, 1, 8, [cols[1][1 + 8 * j] for j in range(8)]), (0, 0, 4, [cols[0][4 * j] for j in range(16)]),
+         (0, 1, 8, [cols[0][1 + 8 * j] for j in range(8)])]
+    D = 2
+    cc_b = _rand_e(fld, len(A), D, 91)
+    zero_t = fld.pack([0] * (2 * D))
+    wire = [(c, f, s, fld.pack([new(v) for v in vals])) for c, f, s, vals in A]
+    out = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, zero_t, wire,
+                                         fld.pack(sum(cc_b, [])))
+    out = [canon(v) for v in fld.unpack(out)]
+    g, g_ce, off = canon(fld.root_of_unity(6)), canon(fld.root_of_unity(7)), canon(offset)
+    ccb = [[canon(v) for v in e] for e in cc_b]
+    ce = n * ce_blowup
+    lde_rows = [[canon(v) for v in fld.unpack(lde[i * (lde_blowup // ce_blowup)][:2 * W])] for i in range(ce)]
+    bpolys = [None if len(vals) == 1 else _value_poly(vals, M, pow(g, s, M)) for _, _, s, vals in A]
+    for i in range(ce):
+        x = off * pow(g_ce, i, M) % M
+        groups = {}
+        for a, (c, first, stride, vals) in enumerate(A):
+            k = n // stride if stride else 1
+            if bpolys[a] is None:
+                b = vals[0]
+            else:
+                y = x * pow(g, (-first) % n, M) % M
+                b = sum(cf * pow(y, m, M) for m, cf in enumerate(bpolys[a])) % M
+            ev = (lde_rows[i][c] - b) % M
+            num = groups.setdefault((stride, first), [[0] * D, (pow(x, k, M) - pow(g, first * k % n, M)) % M])
+            num[0] = [(num[0][d] + ccb[a][d] * ev) % M for d in range(D)]          # coefficient (E) times base value
+        want = [sum(nm[d] * pow(z, M - 2, M) for nm, z in groups.values()) % M for d in range(D)]
+        assert out[i * D:(i + 1) * D] == want, i
+    # the all-single case through the new entry point is the old entry point
+    S = [(0, 0, 0, [1]), (1, 0, 0, [1]), (1, n - 1, 0, [cols[1][n - 1]])]
+    cc_t, cc_s = _rand_e(fld, 2, D, 5), _rand_e(fld, 3, D, 6)
+    a1 = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack(sum(cc_t, [])),
+                                        [(c, f, s, fld.pack([new(v) for v in vals])) for c, f, s, vals in S], fld.pack(sum(cc_s, [])))
+    a2 = fld.evaluate_constraints(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack(sum(cc_t, [])),
+                                  [(c, f, fld.pack([new(vals[0])])) for c, f, s, vals in S], fld.pack(sum(cc_s, [])))
+    assert np.array_equal(a1, a2)
+    # a VALID set (single + sequences that hold on the trace): the combined evaluations are a polynomial of degree < n (exact divisibility)
+    V = [A[0], A[2], A[3], A[4]]
+    cc_v = _rand_e(fld, len(V), D, 8)
+    ok = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack(sum(cc_t, [])),
+                                        [(c, f, s, fld.pack([new(v) for v in vals])) for c, f, s, vals in V], fld.pack(sum(cc_v, [])))
+    co = np.asarray(fld.interpolate_poly_with_offset(ok, offset, D)).reshape(ce, D * W)
+    assert not co[n:].any() and co[:n].any()
+    bad = [V[0], (1, 1, 8, [v + (j == 3) for j, v in enumerate(V[1][3])]), V[2], V[3]]      # one wrong value in a sequence
+    nok = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack(sum(cc_t, [])),
+                                         [(c, f, s, fld.pack([new(v % M) for v in vals])) for c, f, s, vals in bad], fld.pack(sum(cc_v, [])))
+    assert np.asarray(fld.interpolate_poly_with_offset(nok, offset, D)).reshape(ce, D * W)[n:].any()

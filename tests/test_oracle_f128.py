@@ -1,5 +1,6 @@
 """Pin the oracle's f128 restatement (math/src/field/f128/mod.rs) and the field-generic template."""
 import numpy as np
+import pytest
 
 from conftest import P, splitmix64
 
@@ -92,3 +93,46 @@ def test_f128_trace_commitment_structure(oracle):
         assert f.unpack(lde[r, :2])[0] == f.poly_eval(polys[0], x)
         assert leaves[r].tobytes() == oracle.blake3(lde[r, :6].tobytes())     # raw bytes: IS_CANONICAL (blake/mod.rs:53-57)
     assert np.array_equal(nodes, oracle.merkle_build(0, leaves))
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16])
+def test_apply_drp_equals_folding_in_coefficient_form(oracle, N):
+    """The reference's DEFINITION of the degree-respecting projection (fri/src/folding/mod.rs:46-85, the doc example of apply_drp,
+    there for N = 2 over f128): folding the polynomial in coefficient form — f'(x) = sum_k alpha^k f_k(x), f_k = the coefficients
+    = k (mod N) — and evaluating f' over the folded domain {offset^N w^i} gives what apply_drp computes from the transposed
+    evaluations.  Python integers on this side, the oracle's transpose_slice + apply_drp on the other: pins the oracle's FRI fold to
+    the reference's own statement instead of to the in-repo verifier."""
+    import random
+    f, M = oracle.f128, oracle.F128_M
+    rng = random.Random(100 + N)
+    n, deg1 = 8 * N, 2 * N                     # domain of n points, a polynomial with deg1 coefficients (blowup 4)
+    alpha, offset = rng.randrange(M), 3        # BaseElement::GENERATOR of f128 is 3
+    poly = [rng.randrange(M) for _ in range(deg1)]
+    folded = [sum(pow(alpha, k, M) * poly[N * i + k] for k in range(N)) % M for i in range(deg1 // N)]
+    g = int(f.root_of_unity(n.bit_length() - 1))
+    domain = [offset * pow(g, i, M) % M for i in range(n)]
+    gf = pow(g, N, M)
+    fdomain = [pow(offset, N, M) * pow(gf, i, M) % M for i in range(n // N)]
+    ev = [sum(c * pow(x, j, M) for j, c in enumerate(poly)) % M for x in domain]
+    fev = [sum(c * pow(x, j, M) for j, c in enumerate(folded)) % M for x in fdomain]
+    got = f.apply_drp(f.transpose_slice(f.pack(ev), N), N, offset, f.pack([alpha]))
+    assert [int(v) for v in f.unpack(got)] == fev
+
+
+@pytest.mark.parametrize("N", [2, 4, 8, 16])
+def test_apply_drp_definition_over_f64(oracle, N):
+    """the same definitional check for the hand-written f64 fold (oracle/fri.c), Montgomery words in and out"""
+    import random
+    rng = random.Random(200 + N)
+    n, deg1 = 8 * N, 2 * N
+    alpha, offset = rng.randrange(P), 7
+    poly = [rng.randrange(P) for _ in range(deg1)]
+    folded = [sum(pow(alpha, k, P) * poly[N * i + k] for k in range(N)) % P for i in range(deg1 // N)]
+    g = int(oracle.f64_as_int(oracle.f64_root_of_unity(n.bit_length() - 1)))
+    domain = [offset * pow(g, i, P) % P for i in range(n)]
+    fdomain = [pow(offset, N, P) * pow(pow(g, N, P), i, P) % P for i in range(n // N)]
+    ev = [sum(c * pow(x, j, P) for j, c in enumerate(poly)) % P for x in domain]
+    fev = [sum(c * pow(x, j, P) for j, c in enumerate(folded)) % P for x in fdomain]
+    evm = oracle.f64_from_int(np.array(ev, dtype=np.uint64))
+    got = oracle.apply_drp(oracle.transpose_slice(evm, N), N, oracle.f64_new(offset), np.array([oracle.f64_new(alpha)], dtype=np.uint64))
+    assert [int(v) for v in oracle.f64_to_int(got)] == fev

@@ -42,3 +42,16 @@ def test_f62_fft_definition(oracle):
     w = oracle.f62_as_int(f.root_of_unity(6))
     for k in (0, 1, 5, 63):
         assert ev[k] == sum(c * pow(w, k * i, M) for i, c in enumerate(pc)) % M
+
+
+def test_f62_cube_mul_reference_vectors(oracle, golden):
+    """the reference's own fixed vectors for the cubic extension of f62 (math/src/field/f62/tests.rs:128-187: one product within
+    bounds, two "with overflow"), parsed out of the reference's test source by tests/golden/make_golden.py"""
+    f = oracle.f62
+    cases = golden["reference"]["f62_cube_mul"]
+    assert len(cases) == 3 and cases[0]["a"] == [15, 22, 8]
+    for c in cases:
+        o = f.ext_mul(3, [oracle.f62_new(x) for x in c["a"]], [oracle.f62_new(x) for x in c["b"]])
+        assert [oracle.f62_as_int(x) for x in o] == c["out"], c
+        o = f.ext_mul(3, [oracle.f62_new(x) for x in c["b"]], [oracle.f62_new(x) for x in c["a"]])      # commutes
+        assert [oracle.f62_as_int(x) for x in o] == c["out"], c

@@ -76,6 +76,7 @@ def test_wire_primitives(oracle):
 
 
 @pytest.mark.parametrize("name,fname,hid,n,D", [("fib_small", "f64t", 0, 64, 1), ("fib_small", "f64t", 1, 32, 2), ("fib_small", "f64t", 0, 64, 3),
+                                               ("fib_small", "f64t", 0, 1 << 16, 1),       # BASELINE configs[0]: 2^16 rows, the CPU path end to end
                                                ("rescue", "f128", 0, 64, 2), ("rescue", "f128", 0, 128, 1), ("rescue_raps", "f128", 0, 64, 2),
                                                ("rescue_raps", "f128", 0, 128, 1)])
 def test_cpu_prover_proofs_are_accepted(oracle, name, fname, hid, n, D):

@@ -61,6 +61,7 @@ _PROTOS = {
                                   _vp, _vp],
     "wf_rows_fetch": [_vp, _vp, _u64, _u32, _u32, _vp, _u32, _vp],
     "wf_evaluate_constraints": [_vp, _int, _int, _u32, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp],
+    "wf_evaluate_constraints_assertions": [_vp, _int, _int, _u32, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "wf_evaluate_constraints_aux": [_vp, _int, _int, _u32, _vp, _u64, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _vp, _vp,
                                     _u32, _vp, _vp, _vp, _vp, _vp, _vp],
     "wf_polys_evaluate_at": [_vp, _int, _u32, _u32, _vp, _u32, _u64, _u32, _vp, _u32, _vp],

@@ -10,14 +10,59 @@ MIN_BLOWUP_FACTOR = 2          # air/src/options.rs ProofOptions::MIN_BLOWUP_FAC
 
 
 class Assertion:
-    """Assertion::single(column, step, value) (air/src/air/assertions/mod.rs:76-85); stride 0, one value."""
+    """air/src/air/assertions/mod.rs:37-120: Assertion { column, first_step, stride, values }.  single: stride 0, one value;
+    periodic: one value every `stride` steps from `first_step`; sequence: values[i] at first_step + i * stride."""
 
-    def __init__(self, column, step, value):
-        self.column, self.first_step, self.stride, self.value = column, step, 0, value
+    def __init__(self, column, step, value, stride=0, values=None):
+        self.column, self.first_step, self.stride = column, step, stride
+        self.values = [value] if values is None else list(values)
+        self.value = self.values[0]
 
     @classmethod
     def single(cls, column, step, value):
         return cls(column, step, value)
+
+    @staticmethod
+    def _validate_stride(stride, first_step, column):
+        assert stride & (stride - 1) == 0 and stride > 0, "invalid assertion for column %d: stride must be a power of two, but was %d" % (column, stride)
+        assert stride >= 2, "invalid assertion for column %d: stride must be at least 2, but was %d" % (column, stride)     # MIN_STRIDE_LENGTH
+        assert first_step < stride, "invalid assertion for column %d: first step must be smaller than stride (%d steps), but was %d" % (
+            column, stride, first_step)
+
+    @classmethod
+    def periodic(cls, column, first_step, stride, value):
+        """assertions/mod.rs:84-98"""
+        cls._validate_stride(stride, first_step, column)
+        return cls(column, first_step, value, stride)
+
+    @classmethod
+    def sequence(cls, column, first_step, stride, values):
+        """assertions/mod.rs:100-123: a one-value sequence is a single assertion (stride NO_STRIDE)"""
+        cls._validate_stride(stride, first_step, column)
+        values = list(values)
+        assert len(values) > 0, "invalid assertion for column %d: number of asserted values must be greater than zero" % column
+        assert len(values) & (len(values) - 1) == 0, "invalid assertion for column %d: number of asserted values must be a power of two, but was %d" % (
+            column, len(values))
+        return cls(column, first_step, values[0], 0 if len(values) == 1 else stride, values)
+
+    def is_single(self):
+        return self.stride == 0
+
+    def is_periodic(self):
+        return self.stride != 0 and len(self.values) == 1
+
+    def is_sequence(self):
+        return len(self.values) > 1
+
+    def get_num_steps(self, trace_length):
+        """assertions/mod.rs:283-297"""
+        if self.is_single():
+            return 1
+        if self.is_periodic():
+            assert self.stride <= trace_length, "invalid trace length"
+            return trace_length // self.stride
+        assert len(self.values) * self.stride == trace_length, "invalid trace length"
+        return len(self.values)
 
     def sort_key(self):
         """Ord for Assertion: stride, then first_step, then column (assertions/mod.rs:301-315)."""

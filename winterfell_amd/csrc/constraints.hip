@@ -217,10 +217,17 @@ struct AirRescueRaps {
 
 // zb[q][i] = 1 / (x_i - b_q),  x_i = offset * g_ce^i  (series table),  INV_CHUNK consecutive i per lane, one field inversion per
 // workgroup (batch_inv.cuh)
+// multi-value assertions (Assertion::periodic / ::sequence): group q's divisor is x^k - g^(first_step k) with k = 2^log_k[q] asserted steps
+// (air/src/air/divisor.rs:64-97); log_k = 0 is the single-value case x - g^step
+struct GroupLogK {
+    uint32_t v[8];
+};
+static_assert(sizeof(GroupLogK) == 32, "one entry per boundary group");
+
 template <class F>
 __global__ __launch_bounds__(256) void divisor_inv_kernel(const typename F::T *x_lo, const typename F::T *x_hi, uint32_t x_log_lo,
                                                           uint64_t ce, const typename F::T *b, typename F::T one, uint64_t e_lo,
-                                                          uint64_t e_hi, typename F::T *zb) {
+                                                          uint64_t e_hi, GroupLogK log_k, typename F::T *zb) {
     typedef typename F::T T;
     __shared__ T sA[256], sB[256];
     const uint64_t i0 = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * INV_CHUNK;
@@ -232,7 +239,9 @@ __global__ __launch_bounds__(256) void divisor_inv_kernel(const typename F::T *x
 #pragma unroll
     for (int k = 0; k < INV_CHUNK; k++) {
         if ((uint32_t)k < cnt) {
-            v[k] = F::sub(series_at<F>(x_lo, x_hi, x_log_lo, i0 + k), bq);
+            T xv = series_at<F>(x_lo, x_hi, x_log_lo, i0 + k);
+            for (uint32_t sq = 0; sq < log_k.v[q]; sq++) xv = F::mul(xv, xv);        // x^k, k a power of two
+            v[k] = F::sub(xv, bq);
             pre[k] = acc;
             acc = F::mul(acc, v[k]);
         }
@@ -262,6 +271,8 @@ struct EvalParams {
     uint32_t num_assert, ngroups;
     const uint32_t *a_col, *a_group;
     const T *a_val;               // [num_assert]
+    const uint32_t *a_seq;        // [num_assert]: index of the assertion's value vector in `seq`, or ~0u for a constant value (a_val)
+    const T *seq;                 // [sequences][ce]: b(x_i g^(-first_step)) of the sequence assertions over the ce domain
     const T *cc_b;                // [num_assert][D]
     // the auxiliary segment (AIR::AUX_WIDTH > 0): rows of AUX_WIDTH elements of E
     const T *aux_lde;
@@ -350,7 +361,8 @@ __global__ __launch_bounds__(256) void constraints_kernel(EvalParams<typename F:
             const uint32_t col = p.a_col[k];
 #pragma unroll
             for (int c = 1; c < AIR::WIDTH; c++) sv = col == (uint32_t)c ? cur[c] : sv;
-            const T ev = F::sub(sv, p.a_val[k]);
+            const uint32_t sq = p.a_seq[k];
+            const T ev = F::sub(sv, sq == ~0u ? p.a_val[k] : p.seq[(uint64_t)sq * ce + step]);
 #pragma unroll
             for (int d = 0; d < D; d++) grp[d] = F::add(grp[d], F::mul(p.cc_b[k * D + d], ev));
         }
@@ -444,10 +456,23 @@ struct AuxArgs {
     const void *h_vals = nullptr, *h_cc = nullptr, *h_rand = nullptr;
 };
 
+// assertions of every kind against the main segment (wf_evaluate_constraints_assertions): per assertion the stride (0 = single value)
+// and the number of values; h_vals then holds all values back to back.  Null pointers: every assertion is Assertion::single.
+struct MultiArgs {
+    const uint64_t *h_strides = nullptr, *h_nvals = nullptr;
+};
+
+// pool blocks that go back to the context's pool on every way out (stream-ordered: safe right after the launches that use them)
+struct PoolBlocks {
+    wf_ctx *ctx;
+    std::vector<void *> v;
+    ~PoolBlocks() { for (void *p : v) (void)wf_free(ctx, p); }
+};
+
 template <class HF, class AIR, int D>
 static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup,
                     const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols, const uint64_t *h_steps,
-                    const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs()) {
+                    const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs(), const MultiArgs &multi = MultiArgs()) {
     typedef typename HF::T T;
     typedef typename HF::Dev F;
     if ((AIR::AUX_WIDTH > 0) != (aux.d_lde != nullptr)) return WF_ERR_INVALID_ARG;     // a multi-segment AIR comes with its aux segment, the others without
@@ -466,34 +491,81 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     const T g_ce = HF::root_of_unity(log_ce), g_trace = HF::root_of_unity(log_n);
     const T one_c = HF::from_u64(1);
 
-    // boundary groups by asserted step
-    uint64_t gsteps[MAX_GROUPS];
+    // boundary groups by (asserted first step, stride): BoundaryConstraints::new groups by divisor (air/src/air/boundary/mod.rs:168-186)
+    uint64_t gsteps[MAX_GROUPS], gstride[MAX_GROUPS];
+    GroupLogK glogk{};
     uint32_t ngroups = 0;
-    std::vector<uint32_t> a_group(num_assert), a_col(num_assert);
+    std::vector<uint32_t> a_group(num_assert), a_col(num_assert), a_seq(num_assert, ~0u);
     std::vector<T> a_val(num_assert), cc_b((size_t)num_assert * D), cc_t((size_t)(AIR::NT + AIR::NTA) * D);
     std::vector<uint32_t> x_group(aux.num_assert + 1), x_col(aux.num_assert + 1);
     std::vector<T> x_val((size_t)aux.num_assert * D + 1), cc_x((size_t)aux.num_assert * D + 1), rnd((size_t)AIR::NR * D + 1);
+    // sequence assertions: the value polynomial (inverse FFT of the values, BoundaryConstraint::new, constraint.rs:60-91) evaluated at
+    // x g^(-first_step) over the whole constraint-evaluation domain = one coset LDE of 2^log_k coefficients per assertion, on the device
+    T *d_seq = nullptr;
+    uint32_t nseq = 0;
+    PoolBlocks pool{ctx, {}};
+    uint64_t voff = 0;
     for (uint32_t k = 0; k < num_assert; k++) {
+        const uint64_t stride = multi.h_strides ? multi.h_strides[k] : 0, nvals = multi.h_nvals ? multi.h_nvals[k] : 1;
         if (h_cols[k] >= (uint32_t)AIR::WIDTH || h_steps[k] >= n) return WF_ERR_INVALID_ARG;
+        // air/src/air/assertions/mod.rs:84-120: the stride is a power of two >= 2 and <= trace length, first_step < stride; one value
+        // (periodic) or trace_length / stride of them (sequence)
+        if (stride == 0 ? nvals != 1 : ((stride & (stride - 1)) || stride < 2 || stride > n || h_steps[k] >= stride || (nvals != 1 && nvals != n / stride)))
+            return WF_ERR_INVALID_ARG;
         uint32_t q = 0;
-        while (q < ngroups && gsteps[q] != h_steps[k]) q++;
+        while (q < ngroups && (gsteps[q] != h_steps[k] || gstride[q] != stride)) q++;
         if (q == ngroups) {
             if (ngroups == MAX_GROUPS) return WF_ERR_UNSUPPORTED;
-            gsteps[ngroups++] = h_steps[k];
+            gsteps[ngroups] = h_steps[k];
+            gstride[ngroups] = stride;
+            uint32_t lk = 0;
+            while (stride && (stride << lk) < n) lk++;
+            glogk.v[ngroups++] = lk;                                            // k = n / stride asserted steps (1 for a single value)
         }
         a_group[k] = q;
         a_col[k] = h_cols[k];
-        memcpy((void *)&a_val[k], (const uint8_t *)h_vals + (size_t)k * sizeof(T), sizeof(T));
+        memcpy((void *)&a_val[k], (const uint8_t *)h_vals + (size_t)voff * sizeof(T), sizeof(T));
         if (!HF::valid_internal(a_val[k])) return WF_ERR_INVALID_ARG;
         a_val[k] = HF::to_internal(HF::from_internal(a_val[k]));               // normalise lazy f62 words
+        if (nvals > 1) a_seq[k] = nseq++;
+        voff += nvals;
+    }
+    if (nseq) {
+        void *blk;
+        WF_TRY(wf_malloc(ctx, (size_t)nseq * ce * sizeof(T), &blk));
+        pool.v.push_back(blk);
+        d_seq = (T *)blk;
+        const T g_inv = HF::invmod(g_trace);
+        voff = 0;
+        for (uint32_t k = 0; k < num_assert; k++) {
+            const uint64_t nvals = multi.h_nvals[k];
+            if (nvals > 1) {
+                uint32_t lk = 0;
+                while ((1ull << lk) < nvals) lk++;
+                std::vector<T> vals(nvals);
+                memcpy((void *)vals.data(), (const uint8_t *)h_vals + (size_t)voff * sizeof(T), nvals * sizeof(T));
+                for (auto &v : vals) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+                void *d_poly;
+                WF_TRY(wf_malloc(ctx, nvals * sizeof(T), &d_poly));
+                pool.v.push_back(d_poly);
+                WF_TRY(wf_copy_h2d(ctx, d_poly, vals.data(), nvals * sizeof(T)));
+                WF_TRY(wf_fft_interpolate_poly(ctx, HF::Dev::ID, 1, d_poly, lk, 1));
+                // b(x g^(-first_step)) for x = offset g_ce^i: the evaluations of the polynomial over the coset offset g^(-first_step) <g_ce>
+                const T shifted = HF::to_internal(HF::mulmod(off, HF::powmod(g_inv, h_steps[k])));
+                WF_TRY(wf_fft_evaluate_poly_with_offset(ctx, HF::Dev::ID, 1, d_poly, lk, &shifted, log_ce - lk, d_seq + (size_t)a_seq[k] * ce));
+            }
+            voff += nvals;
+        }
     }
     for (uint32_t k = 0; k < aux.num_assert; k++) {                            // aux assertions join the group of their step (boundary.rs:58-73)
         if (aux.h_cols[k] >= (uint32_t)AIR::AUX_WIDTH || aux.h_steps[k] >= n) return WF_ERR_INVALID_ARG;
         uint32_t q = 0;
-        while (q < ngroups && gsteps[q] != aux.h_steps[k]) q++;
+        while (q < ngroups && (gsteps[q] != aux.h_steps[k] || gstride[q] != 0)) q++;
         if (q == ngroups) {
             if (ngroups == MAX_GROUPS) return WF_ERR_UNSUPPORTED;
-            gsteps[ngroups++] = aux.h_steps[k];
+            gsteps[ngroups] = aux.h_steps[k];
+            gstride[ngroups] = 0;
+            glogk.v[ngroups++] = 0;
         }
         x_group[k] = q;
         x_col[k] = aux.h_cols[k];
@@ -524,7 +596,8 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     }
     const T exempt = HF::to_internal(HF::powmod(g_trace, n - 1));
     std::vector<T> bvals(ngroups);
-    for (uint32_t q = 0; q < ngroups; q++) bvals[q] = HF::to_internal(HF::powmod(g_trace, gsteps[q]));
+    for (uint32_t q = 0; q < ngroups; q++)      // g^(first_step k): get_trace_domain_value_at(trace_length, num_steps * first_step), divisor.rs:88-96
+        bvals[q] = HF::to_internal(HF::powmod(g_trace, (gsteps[q] << glogk.v[q]) & (n - 1)));
 
     // periodic table (periodic_table.rs:24-75): column polynomial (inverse DFT of the cycle values) evaluated at
     // offset^(n/cycle) * g_plen^i, i < plen = cycle * ce_blowup; laid out [i][column]
@@ -565,13 +638,14 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     // device staging: one scratch block
     const size_t w_zb = (size_t)ngroups * ce, w_small = ptab.size() + zt.size() + bvals.size() + a_val.size() + cc_b.size() + cc_t.size() +
                                                         x_val.size() + cc_x.size() + rnd.size();
-    const size_t bytes = (w_zb + w_small) * sizeof(T) + 2 * ((size_t)num_assert + x_col.size()) * sizeof(uint32_t) + 64;
+    const size_t bytes = (w_zb + w_small) * sizeof(T) + (3 * (size_t)num_assert + 2 * x_col.size()) * sizeof(uint32_t) + 64;
     void *tmp;
     WF_TRY(wf_scratch(ctx, 0, bytes, &tmp));
     T *d_zb = (T *)tmp, *d_ptab = d_zb + w_zb, *d_zt = d_ptab + ptab.size(), *d_b = d_zt + zt.size(), *d_aval = d_b + bvals.size(),
       *d_ccb = d_aval + a_val.size(), *d_cct = d_ccb + cc_b.size(), *d_xval = d_cct + cc_t.size(), *d_ccx = d_xval + x_val.size(),
       *d_rnd = d_ccx + cc_x.size();
-    uint32_t *d_acol = (uint32_t *)(d_rnd + rnd.size()), *d_agrp = d_acol + num_assert, *d_xcol = d_agrp + num_assert, *d_xgrp = d_xcol + x_col.size();
+    uint32_t *d_acol = (uint32_t *)(d_rnd + rnd.size()), *d_agrp = d_acol + num_assert, *d_xcol = d_agrp + num_assert, *d_xgrp = d_xcol + x_col.size(),
+             *d_aseq = d_xgrp + x_col.size();
     WfUploadBatch batch(ctx, d_ptab);             // everything from d_ptab on is host data: one staged copy
     auto up = [&](void *dst, const void *src, size_t nbytes) { batch.add(dst, src, nbytes); };
     up(d_ptab, ptab.data(), ptab.size() * sizeof(T));
@@ -582,6 +656,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     up(d_cct, cc_t.data(), cc_t.size() * sizeof(T));
     up(d_acol, a_col.data(), num_assert * sizeof(uint32_t));
     up(d_agrp, a_group.data(), num_assert * sizeof(uint32_t));
+    up(d_aseq, a_seq.data(), num_assert * sizeof(uint32_t));
     if (AIR::AUX_WIDTH > 0) {
         up(d_xval, x_val.data(), x_val.size() * sizeof(T));
         up(d_ccx, cc_x.data(), cc_x.size() * sizeof(T));
@@ -600,7 +675,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
         const uint64_t lanes = (ce + INV_CHUNK - 1) / INV_CHUNK;
         wf_prof_begin(ctx, "divisor_inv");
         hipLaunchKernelGGL((divisor_inv_kernel<F>), dim3((uint32_t)((lanes + 255) / 256), ngroups), dim3(256), 0, ctx->stream,
-                           (const T *)xs.d_lo, (const T *)xs.d_hi, xs.log_lo, ce, (const T *)d_b, one_i, e_lo, e_hi, d_zb);
+                           (const T *)xs.d_lo, (const T *)xs.d_hi, xs.log_lo, ce, (const T *)d_b, one_i, e_lo, e_hi, glogk, d_zb);
         wf_prof_end(ctx);
         WF_HIP(hipGetLastError());
     }
@@ -624,6 +699,8 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.a_col = d_acol;
     p.a_group = d_agrp;
     p.a_val = d_aval;
+    p.a_seq = d_aseq;
+    p.seq = d_seq;
     p.cc_b = d_ccb;
     p.aux_lde = (const T *)aux.d_lde;
     p.aux_row_width = aux.row_width;
@@ -646,36 +723,25 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
 template <class HF, class AIR>
 static int evaluate_d(wf_ctx *ctx, uint32_t D, const void *d_lde, uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup,
                       uint32_t log_ce_blowup, const void *h_offset, const void *h_cc_t, uint32_t num_assert, const uint32_t *h_cols,
-                      const uint64_t *h_steps, const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs()) {
-    if (D == 1) return evaluate<HF, AIR, 1>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
-    if (D == 2) return evaluate<HF, AIR, 2>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
+                      const uint64_t *h_steps, const void *h_vals, const void *h_cc_b, void *d_out, const AuxArgs &aux = AuxArgs(),
+                      const MultiArgs &multi = MultiArgs()) {
+    if (D == 1) return evaluate<HF, AIR, 1>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux, multi);
+    if (D == 2) return evaluate<HF, AIR, 2>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux, multi);
     if constexpr (HF::Dev::MAX_EXT >= 3)
-        if (D == 3) return evaluate<HF, AIR, 3>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux);
+        if (D == 3) return evaluate<HF, AIR, 3>(ctx, d_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_offset, h_cc_t, num_assert, h_cols, h_steps, h_vals, h_cc_b, d_out, aux, multi);
     return WF_ERR_UNSUPPORTED;
 }
 
 }  // namespace
 
-extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
-                                       uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
-                                       const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
-                                       const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
-                                       void *d_out) {
-    WF_ENTER(ctx);
-    if (!ctx || !d_trace_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps || !h_assert_values ||
-        !h_cc_boundary || !d_out)
-        return WF_ERR_INVALID_ARG;
+static int evaluate_single_segment(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                   uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                   const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                   const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary, void *d_out,
+                                   const MultiArgs &multi) {
 #define WF_EVAL(HF, AIR)                                                                                                          \
     return evaluate_d<HF, AIR>(ctx, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,    \
-                               h_cc_transition, num_assertions, h_assert_columns, h_assert_steps, h_assert_values, h_cc_boundary, d_out)
-    if (air == WF_AIR_FIB_SMALL) {
-        switch (field) {
-            case WF_FIELD_F64: WF_EVAL(HostF64, AirFibSmall);
-            case WF_FIELD_F128: WF_EVAL(HostF128, AirFibSmall);
-            case WF_FIELD_F62: WF_EVAL(HostF62, AirFibSmall);
-            default: return WF_ERR_UNSUPPORTED;
-        }
-    }
+                               h_cc_transition, num_assertions, h_assert_columns, h_assert_steps, h_assert_values, h_cc_boundary, d_out, AuxArgs(), multi)
 #define WF_EVAL_ANY_FIELD(AIR)                                  \
     switch (field) {                                            \
         case WF_FIELD_F64: WF_EVAL(HostF64, AIR);               \
@@ -683,6 +749,7 @@ extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t
         case WF_FIELD_F62: WF_EVAL(HostF62, AIR);               \
         default: return WF_ERR_UNSUPPORTED;                     \
     }
+    if (air == WF_AIR_FIB_SMALL) { WF_EVAL_ANY_FIELD(AirFibSmall) }
     if (air == WF_AIR_FIB8) { WF_EVAL_ANY_FIELD(AirFib8) }
     if (air == WF_AIR_MULFIB2) { WF_EVAL_ANY_FIELD(AirMulFib2) }
     if (air == WF_AIR_MULFIB8) { WF_EVAL_ANY_FIELD(AirMulFib8) }
@@ -695,6 +762,38 @@ extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t
     }
 #undef WF_EVAL
     return WF_ERR_UNSUPPORTED;
+}
+
+extern "C" int wf_evaluate_constraints(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                       uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                       const void *h_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                       const uint64_t *h_assert_steps, const void *h_assert_values, const void *h_cc_boundary,
+                                       void *d_out) {
+    WF_ENTER(ctx);
+    if (!d_trace_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_steps || !h_assert_values || !h_cc_boundary ||
+        !d_out)
+        return WF_ERR_INVALID_ARG;
+    return evaluate_single_segment(ctx, air, field, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,
+                                   h_cc_transition, num_assertions, h_assert_columns, h_assert_steps, h_assert_values, h_cc_boundary, d_out,
+                                   MultiArgs());
+}
+
+extern "C" int wf_evaluate_constraints_assertions(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde,
+                                                  uint64_t row_width, uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup,
+                                                  const void *h_domain_offset, const void *h_cc_transition, uint32_t num_assertions,
+                                                  const uint32_t *h_assert_columns, const uint64_t *h_assert_first_steps,
+                                                  const uint64_t *h_assert_strides, const uint64_t *h_assert_num_values,
+                                                  const void *h_assert_values, const void *h_cc_boundary, void *d_out) {
+    WF_ENTER(ctx);
+    if (!d_trace_lde || !h_domain_offset || !h_cc_transition || !h_assert_columns || !h_assert_first_steps || !h_assert_strides ||
+        !h_assert_num_values || !h_assert_values || !h_cc_boundary || !d_out)
+        return WF_ERR_INVALID_ARG;
+    MultiArgs multi;
+    multi.h_strides = h_assert_strides;
+    multi.h_nvals = h_assert_num_values;
+    return evaluate_single_segment(ctx, air, field, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,
+                                   h_cc_transition, num_assertions, h_assert_columns, h_assert_first_steps, h_assert_values, h_cc_boundary, d_out,
+                                   multi);
 }
 
 extern "C" int wf_evaluate_constraints_aux(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_main_lde, uint64_t main_row_width,

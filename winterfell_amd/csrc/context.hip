@@ -357,9 +357,9 @@ extern "C" int wf_ctx_create(int device_id, wf_ctx **out) { return ctx_create(de
 extern "C" int wf_ctx_create_on_stream(int device_id, void *hip_stream, wf_ctx **out) { return ctx_create(device_id, false, hip_stream, out); }
 
 extern "C" int wf_ctx_destroy(wf_ctx *ctx) {
-    WF_ENTER(ctx);
     if (!ctx) return WF_ERR_INVALID_ARG;
     {
+    // (no WF_ENTER here: its guard would outlive `delete ctx` below and unlock a mutex in freed memory)
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // a call still running on another thread finishes first
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);

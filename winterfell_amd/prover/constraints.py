@@ -64,6 +64,18 @@ class DefaultConstraintEvaluator:
                      n.bit_length() - 1, domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), nm, vp(cols),
                      vp(steps), vp(vals), vp(ccm), len(self.aux_assertions), vp(xcols), vp(xsteps), vp(xvals), vp(ccx), vp(rnd), ptr(out))
             return out
+        if any(a.stride for a in self.assertions):
+            # periodic / sequence assertions (BoundaryConstraint::new for multi-value assertions, air/src/air/boundary/constraint.rs:60-91):
+            # strides, value counts and all the values back to back
+            for a in self.assertions:
+                a.get_num_steps(n)                                          # validate_trace_length
+            strides = np.array([a.stride for a in self.assertions], dtype=np.uint64)
+            nvals = np.array([len(a.values) for a in self.assertions], dtype=np.uint64)
+            allv = f.pack([v for a in self.assertions for v in a.values])
+            ctx.call("wf_evaluate_constraints_assertions", air.AIR_ID, f.ID, D, ptr(lde.data), lde.row_width, n.bit_length() - 1,
+                     domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), len(self.assertions),
+                     vp(cols), vp(steps), vp(strides), vp(nvals), vp(allv), vp(ccb), ptr(out))
+            return out
         ctx.call("wf_evaluate_constraints", air.AIR_ID, f.ID, D, ptr(lde.data), lde.row_width, n.bit_length() - 1,
                  domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), len(self.assertions),
                  vp(cols), vp(steps), vp(vals), vp(ccb), ptr(out))
