@@ -40,14 +40,14 @@ def measure(name, fn):
     manifest.append({"name": name, "calls": K})
 
 
-def lde_case(key, field, log_rows, cols, parts=1):
+def lde_case(key, field, log_rows, cols, parts=1, hasher=None):
     rows = 1 << log_rows
     if field is fields.f64:
         tr = ctx.to_device(rng.integers(0, fields.M, (cols, rows), dtype=np.uint64))
     else:
         tr = torch.randint(0, 1 << 62, (cols, rows * 2), dtype=torch.int64, device=ctx.device)
     cm, dom, po = prover.ColMatrix(tr, field=field), prover.StarkDomain(rows, 8, field=field), prover.PartitionOptions(parts, 1)
-    measure("lde_commit_" + key, lambda: prover.build_trace_commitment(crypto.Blake3_256, cm, dom, po))
+    measure("lde_commit_" + key, lambda: prover.build_trace_commitment(hasher or crypto.Blake3_256, cm, dom, po))
     del tr, cm
     torch.cuda.empty_cache()
 
@@ -62,6 +62,8 @@ if want("lde_long"):
     lde_case("2^24x4_b8_f64_blake3", fields.f64, 24, 4)
 if want("config3"):
     lde_case("2^22x64_b8_f128_blake3_p8", fields.f128, 22, 64, parts=8)
+if want("lde_rescue"):
+    lde_case("2^20x4_b8_f64_rp64", fields.f64, 20, 4, hasher=crypto.Rp64_256)
 if want("merkle"):
     lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))
     measure("merkle_blake3_2^23_leaves", lambda: crypto.MerkleTree.new(crypto.Blake3_256, lv))

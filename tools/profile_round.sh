@@ -3,7 +3,7 @@
 # Produces under gpurun_out/profiles/<round>/: the plain bench line, the rocprofv3 --kernel-trace --stats summary of the
 # same bench command, and the PMC summary (separate --pmc passes, no tracing options combined with them).
 set -u
-R=${1:-r03}
+R=${1:-r04}
 OUT=gpurun_out/profiles/$R
 RAW=gpurun_out/prof_raw_$R
 mkdir -p "$OUT" "$RAW"
@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 # HBM bytes per call of the workloads behind bench.py's `rooflines` (LDE + commit shapes, Merkle, FRI), counters in separate runs
 rocprofv3 --pmc FETCH_SIZE -d "$RAW/wl_fetch_size" -o $R --output-format csv -- python tools/pmc_workloads.py > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$RAW/wl_write_size" -o $R --output-format csv -- python tools/pmc_workloads.py > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES -d "$RAW/wl_sq" -o $R --output-format csv -- python tools/pmc_workloads.py > /dev/null 2>&1
 python tools/summarize_workloads_pmc.py "$RAW" $R gpurun_out/pmc_workloads_manifest.json > "$OUT/workloads_pmc_summary.json"
 # bench.py quotes these counters as `rooflines.*.traffic`: put this run's summary where it looks (profiles/<round>/ of THIS copy of the repo)
 mkdir -p profiles/$R && cp "$OUT/workloads_pmc_summary.json" profiles/$R/workloads_pmc_summary.json

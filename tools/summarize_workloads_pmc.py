@@ -38,7 +38,35 @@ def per_workload(counter):
     return out
 
 
-fetch, write = per_workload("FETCH_SIZE"), per_workload("WRITE_SIZE")
+def per_workload_sq():
+    """SQ counters of the `wl_sq` pass (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU, SQ_BUSY_CYCLES, SQ_WAVE_CYCLES), summed over the dispatches
+    of a call: bench.py prices a workload's VALU issue floor with them (SQ_ACTIVE_INST_VALU x 4 cycles over 1024 SIMDs)."""
+    paths = glob.glob("%s/wl_sq/**/%s_counter_collection.csv" % (raw, rnd), recursive=True)
+    if not paths:
+        return None
+    rows = defaultdict(dict)
+    with open(paths[0]) as f:
+        for row in csv.DictReader(f):
+            d = rows[int(row["Dispatch_Id"])]
+            d["name"] = row["Kernel_Name"]
+            d[row["Counter_Name"]] = float(row["Counter_Value"])
+    order = sorted(rows)
+    marks = [i for i, k in enumerate(order) if "twiddles_kernel" in rows[k]["name"]]
+    assert len(marks) == 2 * len(manifest), "expected %d markers, found %d" % (2 * len(manifest), len(marks))
+    out = []
+    for w, item in enumerate(manifest):
+        tot, kern = defaultdict(float), defaultdict(lambda: defaultdict(float))
+        for k in order[marks[2 * w] + 1:marks[2 * w + 1]]:
+            short = rows[k]["name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
+            for c, v in rows[k].items():
+                if c != "name":
+                    tot[c] += v / item["calls"]
+                    kern[short][c] += v / item["calls"]
+        out.append((dict(tot), {k: dict(v) for k, v in kern.items()}))
+    return out
+
+
+fetch, write, sq = per_workload("FETCH_SIZE"), per_workload("WRITE_SIZE"), per_workload_sq()
 res = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate runs of tools/pmc_workloads.py; bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 "
                "over all dispatches of a call (torch's own copy / fill kernels between library calls included)", "workloads": {}}
 for i, item in enumerate(manifest):
@@ -54,6 +82,10 @@ for i, item in enumerate(manifest):
         if src:
             for k, v in src[i][3].items():
                 kern.setdefault(k, {"launches_per_call": v["launches_per_call"]})[key] = v["kib_per_call"]
+    if sq:
+        entry["sq"] = sq[i][0]
+        for k, v in sq[i][1].items():
+            kern.setdefault(k, {})["sq"] = v
     entry["kernels"] = kern
     res["workloads"][item["name"]] = entry
 print(json.dumps(res, indent=1))

@@ -233,10 +233,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         divmod_uniform(vs, p.src_inner, vq, vr);
         const T *src = p.src + (uint64_t)vq * p.src_vec_stride + (uint64_t)vr * p.src_inner_stride;
         if (active) {
+            // one 64-bit address per lane; the lane's A inputs follow at a wave-uniform stride (scalar arithmetic), so an element
+            // costs one address instruction instead of a 64-bit multiply by the element stride (ten)
+            const T *ptr = src + (base + ((uint64_t)b1 << log_s)) * p.src_es;
+            const uint64_t istep = ((uint64_t)B << log_s) * p.src_es;
 #pragma unroll
             for (int a = 0; a < A; a++) {
-                const uint64_t j = base + ((uint64_t)(a * B + b1) << log_s);
-                xin[a] = F::load_norm(src[j * p.src_es]);
+                xin[a] = F::load_norm(*ptr);
+                ptr += istep;          // a running pointer: one shift-add with the scalar step (a * istep becomes multiply-adds)
             }
         } else {
 #pragma unroll
@@ -376,30 +380,64 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     const uint64_t rem = c & ((1ull << log_s) - 1);
     const uint64_t base_nl = ((c >> log_s) << (log_s + LOG_R)) + rem;
 
-    auto emit = [&](T val, uint32_t kp) {
+    // Output addressing: every output of a lane is  kp = kbase + krel  with kbase per lane (the k_a of its B-point DFT, or 0) and
+    // krel a compile-time multiple of the unrolled loops, so its address is  o_ptr + krel * o_step  with ONE 64-bit pointer per lane
+    // and a wave-uniform step (scalar arithmetic): one address instruction per element.  (The form  dst[(base + (kp << log_s)) *
+    // dst_es]  cost a 64-bit multiply per element — two multiply-adds, moves, two shift-adds — and kept sixteen pointers live.)
+    T *o_ptr = nullptr, *o_ptr0 = nullptr;      // o_ptr0: the krel = 0 output (differs for the inverse transform's k = 0 wrap)
+    int64_t o_step = 0;                         // elements of T per unit of krel (negative when the output index runs backwards)
+    const T *tw0 = nullptr;                     // TWTAB: the table entry of krel = 0 for this lane's column
+    uint32_t o_k32 = 0, o_kstep32 = 0;          // natural output index of krel = 0 and its step (last pass: post-scale look-ups)
+    auto set_out_base = [&](uint32_t kbase) {
+        if constexpr (!LAST) {
+            o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
+            o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
+            if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 ? 4 : 1) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
+        } else if (RM) {
+            // LDE row u + b * m, column bc
+            o_ptr = o_ptr0 = p.dst + (u2 + ((c + ncols * (uint64_t)kbase) << p.rm_log_b)) * p.rm_row_width + bc2;
+            o_step = (int64_t)((ncols << p.rm_log_b) * p.rm_row_width);
+        } else {
+            const uint64_t k0 = c + ncols * (uint64_t)kbase;           // natural output index
+            if (p.inverse) {
+                o_ptr = dst + (n - k0) * p.dst_es;                      // k = n - k0 - krel ncols: never wraps for krel > 0
+                o_ptr0 = dst + ((n - k0) & (n - 1)) * p.dst_es;
+                o_step = -(int64_t)(ncols * (uint64_t)p.dst_es);
+                o_k32 = (uint32_t)(n - k0);
+                o_kstep32 = 0u - (uint32_t)ncols;
+            } else {
+                o_ptr = o_ptr0 = dst + k0 * p.dst_es;
+                o_step = (int64_t)(ncols * (uint64_t)p.dst_es);
+                o_k32 = (uint32_t)k0;
+                o_kstep32 = (uint32_t)ncols;
+            }
+        }
+    };
+    // the unrolled loops walk krel = 0, s, 2 s, ... in order: a running pointer, one shift-add with a scalar operand per output
+    auto out_next = [&](bool first, int64_t stride) -> T * {
+        if (first) return o_ptr0;
+        o_ptr += stride;
+        return o_ptr;
+    };
+    auto emit = [&](T val, uint32_t kp, uint32_t krel, int64_t stride) {
         if constexpr (RH) {
             lds[kp * TC + t2] = val;        // staged: [output digit k'][tile column], rows are taken from here below
             return;
         }
-        if (!LAST) {
-            if (kp != 0) {
-                const uint32_t e = (kp * (uint32_t)rem) << log_mult;   // < n <= 2^32
-                val = F::mul(val, series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, e));
-            }
-            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val;
-        } else if (RM) {
-            // LDE row u + b * m, column bc; the last group's lanes also zero the padding columns of that row
-            T *row = p.dst + (u2 + ((c + ncols * (uint64_t)kp) << p.rm_log_b)) * p.rm_row_width;
-            if (real_col) row[bc2] = val;
+        if (RM) {
+            // the last group's lanes also zero the padding columns of that row
+            T *cell = out_next(krel == 0, stride);
+            if (real_col) *cell = val;
             if ((bc2 >> p.rm_log_i) + 1 == rm_groups) {
+                T *row = cell - bc2;
                 for (uint64_t pc = p.rm_base_cols + (bc2 & ((1u << p.rm_log_i) - 1)); pc < p.rm_row_width; pc += 1u << p.rm_log_i) row[pc] = F::zero();
             }
         } else {
-            uint64_t k = c + ncols * (uint64_t)kp;           // natural output index
-            if (p.inverse) k = (n - k) & (n - 1);
-            if (p.post_lo != nullptr) val = F::mul(val, series_at32<F>(p.post_lo, p.post_hi, p.post_log_lo, (uint32_t)k));
-            else if (p.has_post_const && !p.scale_in_w256) val = F::mul(val, p.post_const);
-            dst[k * p.dst_es] = val;
+            if (p.post_lo != nullptr) {
+                const uint32_t k = (o_k32 + krel * o_kstep32) & (uint32_t)(n - 1);
+                val = F::mul(val, series_at32<F>(p.post_lo, p.post_hi, p.post_log_lo, k));
+            } else if (p.has_post_const && !p.scale_in_w256) val = F::mul(val, p.post_const);
+            *out_next(krel == 0, stride) = val;
         }
     };
 
@@ -412,6 +450,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         constexpr int LOG_CNT = decltype(log_cnt_tag)::value;
         constexpr int CNT = 1 << LOG_CNT;
         const uint32_t r32 = (uint32_t)rem;
+        set_out_base(k0);
         if constexpr (TWTAB) {
             // small strides: the pass's 2^(LOG_R + log_s) twiddles sit in one L2-resident table, rows of 2^log_s consecutive
             // `rem` (a tile's 16 columns = one 128-byte run): 16 coalesced loads replace the 15-multiplication chain
@@ -419,7 +458,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             for (int ip = 0; ip < CNT; ip++) {
                 const int i = brev(ip, LOG_CNT);
                 const uint32_t kp = k0 + step_k * (uint32_t)ip;
-                dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(val(i), p.tw_tab[((uint64_t)kp << log_s) + r32]);
+                (void)kp;
+                *out_next(ip == 0, (int64_t)step_k * o_step) = F::mul(val(i), tw0[((uint64_t)(step_k * (uint32_t)ip)) << log_s]);
             }
             return;
         }
@@ -436,9 +476,11 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             const int i = brev(ip, LOG_CNT);                 // register holding output digit ip
             const uint32_t kp = k0 + step_k * (uint32_t)ip;
 #ifdef NTT_EXPERIMENT_NO_CHAIN    // timing experiments only
-            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = val(i) ^ cur ^ stp;
+            (void)kp;
+            *out_next(ip == 0, (int64_t)step_k * o_step) = val(i) ^ cur ^ stp;
 #else
-            dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = F::mul(val(i), cur);
+            (void)kp;
+            *out_next(ip == 0, (int64_t)step_k * o_step) = F::mul(val(i), cur);
             if (ip + 1 < CNT) cur = F::mul(cur, stp);
 #endif
         }
@@ -448,8 +490,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         if constexpr (!LAST) {
             emit_progression([&](int i) { return x[i]; }, 0u, 1u, std::integral_constant<int, LOG_A>{});
         } else {
+            set_out_base(0u);
 #pragma unroll
-            for (int i = 0; i < A; i++) emit(x[i], (uint32_t)brev(i, LOG_A));
+            for (int ip = 0; ip < A; ip++) emit(x[brev(ip, LOG_A)], (uint32_t)ip, (uint32_t)ip, o_step);
         }
     } else {
 #pragma unroll
@@ -472,7 +515,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #endif
                 if constexpr (TWTAB) {
                     // inter-pass twiddles from the L2-resident table, kept in the same four-word form: multiply, fold, store
-                    const uint32_t r32 = (uint32_t)rem;
+                    set_out_base((uint32_t)ka);
 #pragma unroll
                     for (int ip = 0; ip < B; ip++) {
                         const int i = brev(ip, LOG_B);
@@ -480,8 +523,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                         uint32_t yl[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) yl[q] = DB::limb(v, i, q);
-                        const T *w = p.tw_tab + 4 * (((uint64_t)kp << log_s) + r32);
-                        dst[(base_nl + ((uint64_t)kp << log_s)) * p.dst_es] = l24::fold(l24::mul4(yl, w[0], w[1], w[2], w[3]));
+                        (void)kp;
+                        const T *w = tw0 + 4 * (((uint64_t)A * (uint32_t)ip) << log_s);
+                        *out_next(ip == 0, (int64_t)A * o_step) = l24::fold(l24::mul4(yl, w[0], w[1], w[2], w[3]));
                     }
                 } else {
                     // leave the limb form one element at a time, right where the value is consumed.  The last pass stores these
@@ -496,8 +540,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                     if constexpr (!LAST) {
                         emit_progression(out, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{}, g);
                     } else {
+                        set_out_base((uint32_t)ka);
 #pragma unroll
-                        for (int i = 0; i < B; i++) emit(out(i), (uint32_t)(ka + A * brev(i, LOG_B)));
+                        for (int ip = 0; ip < B; ip++) emit(out(brev(ip, LOG_B)), (uint32_t)(ka + A * ip), (uint32_t)(A * ip), (int64_t)A * o_step);
                     }
                 }
             } else {
@@ -505,8 +550,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                 if constexpr (!LAST) {
                     emit_progression([&](int i) { return y[i]; }, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
                 } else {
+                    set_out_base((uint32_t)ka);
 #pragma unroll
-                    for (int i = 0; i < B; i++) emit(y[i], (uint32_t)(ka + A * brev(i, LOG_B)));
+                    for (int ip = 0; ip < B; ip++) emit(y[brev(ip, LOG_B)], (uint32_t)(ka + A * ip), (uint32_t)(A * ip), (int64_t)A * o_step);
                 }
             }
         }
