@@ -437,8 +437,8 @@ int wf_comm_all_gather(wf_comm *comm, const void *d_send, void *d_recv, uint64_t
  * digests, the FRI re-stride of fri/src/prover/mod.rs:202-211 over row-range shards) */
 int wf_comm_all_to_all(wf_comm *comm, const void *d_send, void *d_recv, uint64_t bytes);
 /* DefaultTraceLde::new / build_trace_commitment (prover/src/trace/trace_lde/default/mod.rs:63-86,245-282) with the columns
- * sharded by partition: this rank holds partition `rank` (shard_cols columns of 2^log_n evaluations, col_stride words
- * apart).  It interpolates and extends its columns, hashes its part of every LDE row, receives the other partitions'
+ * sharded by partition: this rank holds partition `rank` (shard_cols columns of 2^log_n evaluations, col_stride base-field
+ * ELEMENTS apart, as in wf_build_trace_commitment).  It interpolates and extends its columns, hashes its part of every LDE row, receives the other partitions'
  * digests of ITS row range [rank N/G, (rank+1) N/G), N = 2^(log_n + log_blowup), merges them into leaves, builds the
  * subtree over them, and after the sub-root all-gather the top log2 G levels.  On return (all device memory of this rank):
  * d_trace_shard = polynomials, d_lde_shard = the shard's RowMatrix [N][wf_row_width(shard_cols, ext_degree)],

@@ -46,7 +46,7 @@ def _sharded_commit(ctx0, comms, ctxs, hasher, fld, shards, log_n, log_b, offset
     def run(r):
         try:
             lib, b = ctx0.lib, bufs[r]
-            st = lib.wf_comm_sharded_commit(comms[r], hasher.HASH_ID, fld.ID, D, _vp(b["tr"]), b["c"], n * D * fld.W, log_n, log_b,
+            st = lib.wf_comm_sharded_commit(comms[r], hasher.HASH_ID, fld.ID, D, _vp(b["tr"]), b["c"], n * D, log_n, log_b,   # col_stride: base elements
                                             offset_words.ctypes.data_as(ctypes.c_void_p), 0, _vp(b["lde"]), _vp(b["leaves"]), _vp(b["nodes"]),
                                             _vp(b["top"]), b["root"].ctypes.data_as(ctypes.c_void_p))
             assert st == 0, "wf_comm_sharded_commit -> %d" % st
@@ -342,7 +342,8 @@ def test_a_failing_rank_releases_its_peers(wf, oracle):
         def run(r):
             fld, tr, off, hid = ((f64, tr0, off64, crypto.Blake3_256.HASH_ID), (f128, tr1, off128, crypto.Rp64_256.HASH_ID))[r]
             b = bufs[r]
-            status[r] = lib.wf_comm_sharded_commit(comms[r], hid, fld.ID, 1, _vp(tr), 2, n * fld.W, log_n, log_b, off.ctypes.data_as(ctypes.c_void_p), 0,
+            # col_stride is in base-field ELEMENTS (n for both fields; n * W walked off the end of rank 1's trace: found by the guard session)
+            status[r] = lib.wf_comm_sharded_commit(comms[r], hid, fld.ID, 1, _vp(tr), 2, n, log_n, log_b, off.ctypes.data_as(ctypes.c_void_p), 0,
                                                    _vp(b["lde"]), _vp(b["leaves"]), _vp(b["nodes"]), _vp(b["top"]), None)
 
         ts = [threading.Thread(target=run, args=(r,), daemon=True) for r in range(G)]

@@ -119,7 +119,8 @@ def test_fri_layers_vs_oracle(wf, oracle, D, N):
     rows = (1 << log_len) // N
     tr, leaves, nodes = ctx.empty_u64(rows, N * D * 2), ctx.empty_u8(rows, 32), ctx.empty_u8(rows, 32)
     root = np.empty(32, dtype=np.uint8)
-    ctx.call("wf_fri_layer_commit", 0, f.ID, D, ptr(ctx.to_device(ev)), log_len, N, ptr(tr), ptr(leaves), ptr(nodes),
+    d_ev = ctx.to_device(ev)          # kept alive across the call (the guard session unmaps a tensor the moment it dies)
+    ctx.call("wf_fri_layer_commit", 0, f.ID, D, ptr(d_ev), log_len, N, ptr(tr), ptr(leaves), ptr(nodes),
              root.ctypes.data_as(ctypes.c_void_p))
     o_tr = of.transpose_slice(ev, N, D)
     o_leaves, o_nodes = of.fri_layer_commit(0, o_tr, N, D)

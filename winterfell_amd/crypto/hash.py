@@ -65,8 +65,10 @@ class _Hasher:
         for i, m in enumerate(msgs):
             buf[i, :n] = np.frombuffer(m, dtype=np.uint8)
         d_out = ctx.empty_u8(max(len(msgs), 1), 32)
-        ctx.call("wf_hash_bytes_batch", cls.HASH_ID, ptr(ctx.to_device(buf)), len(msgs), stride, n, ptr(d_out))
+        d_in = ctx.to_device(buf)       # a NAME, alive until the read-back below has waited for the stream: a temporary inside the call
+        ctx.call("wf_hash_bytes_batch", cls.HASH_ID, ptr(d_in), len(msgs), stride, n, ptr(d_out))     # expression dies before the kernel runs
         out = ctx.to_host(d_out)[:len(msgs)]
+        del d_in
         return out[0] if single else out
 
     @classmethod

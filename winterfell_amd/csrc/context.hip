@@ -60,6 +60,10 @@ bool guard_left() {
     }();
     return l;
 }
+bool guard_env_flag(const char *name) {
+    const char *e = getenv(name);
+    return e && e[0] && e[0] != '0';
+}
 struct GuardRec {
     void *va = nullptr;       // reservation (mode 1) or raw hipMalloc pointer (mode 2)
     size_t reserve = 0, mapped = 0, gran = 0, bytes = 0;
@@ -109,6 +113,17 @@ hipError_t guard_alloc(int device, size_t bytes, void **out) {
             return e;
         }
         r.mode = 1;
+        if (guard_env_flag("WF_DEBUG_GUARD_PREFILL")) {
+            // experiment (tools/debug_guard192.py): fill the fresh mapping, wait, and read both ends back before handing it out
+            unsigned char probe[2] = {0, 0};
+            for (int attempt = 0; attempt < 8; attempt++) {
+                if ((e = hipMemset(base, 0x5a, r.mapped)) != hipSuccess || (e = hipDeviceSynchronize()) != hipSuccess) break;
+                (void)hipMemcpy(&probe[0], base, 1, hipMemcpyDeviceToHost);
+                (void)hipMemcpy(&probe[1], base + r.mapped - 1, 1, hipMemcpyDeviceToHost);
+                if (probe[0] == 0x5a && probe[1] == 0x5a) break;
+                fprintf(stderr, "wf guard: fresh mapping at %p lost its fill (attempt %d: %02x %02x)\n", (void *)base, attempt, probe[0], probe[1]);
+            }
+        }
         // 16-byte alignment is what the kernels assume of a caller's buffer (uint4 accesses); hipMalloc would give 256
         *out = guard_left() ? (void *)base : (void *)(base + r.mapped - round_up(bytes, 16));
     } else {
@@ -143,7 +158,13 @@ hipError_t guard_free(void *p) {
         char *base = (char *)r.va + r.gran;
         hipError_t e2 = hipMemUnmap(base, r.mapped);
         hipError_t e3 = hipMemRelease(r.handle);
-        hipError_t e4 = hipMemAddressFree(r.va, r.reserve);
+        // The reservation is KEPT: an address range is never mapped to a second allocation.  With ROCm 7.0 on gfx950 a range that is
+        // unmapped, released, freed, reserved again (the runtime hands out the same address) and mapped to a NEW allocation keeps
+        // serving the GPU stale translations: a fill + hipDeviceSynchronize + read-back of the fresh mapping returns the old
+        // contents, kernels' stores to its first pages are lost (tools/repro_vmem_remap.hip reproduces it without this library;
+        // the first electric-fence session of round 4 failed 7 tests that way and none with the reservations kept).
+        // WF_DEBUG_GUARD_VA_REUSE=1 restores the free for that experiment.  A session leaks address space only (no memory).
+        hipError_t e4 = guard_env_flag("WF_DEBUG_GUARD_VA_REUSE") ? hipMemAddressFree(r.va, r.reserve) : hipSuccess;
         return e != hipSuccess ? e : (e2 != hipSuccess ? e2 : (e3 != hipSuccess ? e3 : e4));
     }
     std::vector<unsigned char> z(2 * RED);

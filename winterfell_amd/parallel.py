@@ -91,7 +91,8 @@ class HipBackend:
         from ._lib import ptr
         rows, k = digests.shape[0], digests.shape[1]
         out = self.ctx.empty_u8(rows, 32)
-        self.ctx.call("wf_hash_merge_many_batch", self.hasher.HASH_ID, ptr(digests.contiguous()), rows, k, ptr(out))
+        digests = digests.contiguous()          # a name: a temporary copy inside the call expression would die before the kernel runs
+        self.ctx.call("wf_hash_merge_many_batch", self.hasher.HASH_ID, ptr(digests), rows, k, ptr(out))
         return out
 
     def merkle_nodes(self, leaves):
@@ -101,7 +102,8 @@ class HipBackend:
         if n == 1:
             return leaves.clone()
         nodes = self.ctx.empty_u8(n, 32)
-        self.ctx.call("wf_merkle_build", self.hasher.HASH_ID, ptr(leaves.contiguous()), n, ptr(nodes))
+        leaves = leaves.contiguous()            # see merge_many_rows
+        self.ctx.call("wf_merkle_build", self.hasher.HASH_ID, ptr(leaves), n, ptr(nodes))
         return nodes
 
 
@@ -280,7 +282,8 @@ class HipFriBackend:
         if n == 1:
             return leaves.clone()
         nodes = self.ctx.empty_u8(n, 32)
-        self.ctx.call("wf_merkle_build", self.hasher.HASH_ID, ptr(leaves.contiguous()), n, ptr(nodes))
+        leaves = leaves.contiguous()            # see merge_many_rows
+        self.ctx.call("wf_merkle_build", self.hasher.HASH_ID, ptr(leaves), n, ptr(nodes))
         return nodes
 
     def finish_unsharded(self, options, channel, vector):
