@@ -24,6 +24,9 @@ import numpy as np
 import torch
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# issue rates of the two VALU instruction classes of this chip, cycles per wave-instruction on one SIMD (tools/microbench_isa.hip,
+# profiles/r02/microbench_isa_*.txt: 2.3-2.7 for plain 32-bit add / sub / and / xor / arithmetic shift / mov, 4.1-4.6 for the rest)
+VALU_FAST_CYCLES, VALU_SLOW_CYCLES = 2.3, 4.3
 
 
 def fail(msg, code=2):
@@ -507,36 +510,41 @@ def main():
                 pmf = json.load(f)
             if args.log_n == 24:
                 traffic = pmf["ntt_2^24_f64"]["hbm_bytes_per_transform"]
-                # the second ceiling: wave-instructions per element and the share of the SIMD-cycles of a launch in which a VALU
-                # instruction issues (SQ_ACTIVE_INST_VALU counts quad-cycles; 1024 SIMDs), from the same counter run
-                insts, act, busy_us = 0.0, 0.0, 0.0
+                # the second bound: wave-instructions per element (SQ_INSTS_VALU; on this chip SQ_ACTIVE_INST_VALU reports the same
+                # number, i.e. it counts instructions, not cycles), priced at the two issue rates below
+                insts = 0.0
                 for kname, cs in pmf["kernels"].items():
                     if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or kname.rstrip().split("(")[0].endswith(", true>"):
                         continue                       # (the rows + leaves variant of the last pass belongs to the LDE, not to a transform)
                     per_transform = 1 if "ntt_pass<F64, 4, 4, true," in kname else 2       # the last pass once, the other shape twice
                     insts += per_transform * cs["SQ_INSTS_VALU"]["avg"] * 64 / n
-                    act += per_transform * cs["SQ_ACTIVE_INST_VALU"]["avg"] * 4
                 if insts:
                     ghz = (sclk_mhz or 2400.0) * 1e-3
-                    valu = {"insts_per_element_per_transform": insts, "active_simd_cycles_per_transform": act,
+                    wave_insts = insts * n / 64.0
+                    valu = {"insts_per_element_per_transform": insts, "wave_insts_per_transform": wave_insts,
                             "clock_ghz": ghz, "clock_source": "measured beside the kernels (wf_debug_shader_clock: s_memtime over s_memrealtime)"
                             if sclk_mhz else "assumed (maximum clock; the probe failed)",
-                            "active_frac": act / (1024 * fwd_us * 1e-6 * ghz * 1e9),
-                            "issue_floor_us_at_100pct": act / (1024 * ghz * 1e9) * 1e6,
-                            "active_frac_at_2.4ghz": act / (1024 * fwd_us * 1e-6 * 2.4e9),
-                            "source": "profiles/%s/bench_pmc_summary.json (SQ_INSTS_VALU, SQ_ACTIVE_INST_VALU x 4 cycles)" % pmc_round}
+                            "issue_us_if_every_inst_were_fast": wave_insts * VALU_FAST_CYCLES / (1024 * ghz * 1e9) * 1e6,
+                            "issue_us_if_every_inst_were_slow": wave_insts * VALU_SLOW_CYCLES / (1024 * ghz * 1e9) * 1e6,
+                            "measured_us": fwd_us,
+                            "what": "SQ_INSTS_VALU (wave-instructions, summed over the transform's launches) priced at the two issue rates "
+                                    "tools/microbench_isa.hip measures on this chip: %.1f cycles per wave-instruction on a SIMD for plain 32-bit "
+                                    "add / sub / and / xor / shift / mov, %.1f for everything else (multiply-adds, carry producers and consumers, "
+                                    "64-bit and three-operand forms).  The first is a hard lower bound of the kernel time, the second what this "
+                                    "stream would cost if none of it were of the fast class; about a third of it is." % (VALU_FAST_CYCLES, VALU_SLOW_CYCLES),
+                            "source": "profiles/%s/bench_pmc_summary.json (SQ_INSTS_VALU)" % pmc_round}
         except Exception:
             traffic = None
         out["roofline"] = {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/%s/bench_pmc_summary.json)" % pmc_round,
             "valu": valu,
-            "limiter": "VALU issue, not HBM: a pass executes ~110-130 wave-instructions per element (limb DFTs, two multiply-accumulate "
-                       "exits, the Montgomery chain of the twiddle progression) and SQ_ACTIVE_INST_VALU x 4 cycles is ~0.8 of the SIMD-cycles "
-                       "of a launch; the same tiles as a pure read-modify-write take 50 us per pass (5.4 TB/s), so three passes cap the "
-                       "fraction at 0.225 with free arithmetic, and the issue floor of the arithmetic at 100 % utilisation is in `valu`; "
-                       "HBM traffic = 1.02x the data per pass, three passes (a two-pass radix-4096 plan needs MORE general multiplications: "
-                       "DESIGN.md section 5)",
+            "limiter": "co-limited by VALU issue and HBM: a pass executes ~90-115 wave-instructions per element (limb DFTs, two "
+                       "multiply-accumulate exits, the Montgomery chain of the twiddle progression; `valu` prices them), and the same tiles "
+                       "as a pure read-modify-write take 50 us per pass (5.4 TB/s), so three passes cap the fraction at 0.225 with free "
+                       "arithmetic.  Round 4 took 13 % of the instructions out (366 -> 317 per element: addresses) and the transform moved by "
+                       "0-4 %: neither bound alone explains the time, their imperfect overlap does.  HBM traffic = 1.02x the data per pass, "
+                       "three passes (a two-pass radix-4096 plan does not fit LDS with 128-byte row segments: DESIGN.md section 5)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
@@ -656,17 +664,20 @@ def main():
                 wl_traffic = {}
 
             def issue(key, ms):
-                """the VALU issue ceiling of a workload from its committed counter run: SQ_ACTIVE_INST_VALU x 4 cycles over the 1024 SIMDs
-                at the clock measured under the leg's load = the kernel time at 100 % issue utilisation; `active_frac` = how much of the
-                measured kernel time that is.  None without a counter run."""
+                """VALU issue time of a workload from its committed counter run, as a bracket: SQ_INSTS_VALU (wave-instructions over
+                all dispatches of a call) at the fast class's issue rate (a hard lower bound of the kernel time) and at the slow class's
+                (tools/microbench_isa.hip), over 1024 SIMDs at the clock measured under the leg's load.  None without a counter run.
+                (Round 3 and the first half of round 4 quoted insts x 4 cycles as a "floor": Rescue then showed 1.2 — not a floor.)"""
                 sq = wl_traffic.get(key, {}).get("sq") if key else None
-                if not sq or not sq.get("SQ_ACTIVE_INST_VALU"):
+                if not sq or not sq.get("SQ_INSTS_VALU"):
                     return None
                 ghz = (last_clock[0] or 2400.0) * 1e-3
-                floor_ms = sq["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * ghz * 1e9) * 1e3
-                return {"valu_insts_per_call": sq.get("SQ_INSTS_VALU"), "active_simd_cycles_per_call": sq["SQ_ACTIVE_INST_VALU"] * 4,
-                        "clock_ghz": ghz, "clock_measured": last_clock[0] is not None, "issue_floor_ms_at_100pct": floor_ms,
-                        "active_frac": floor_ms / ms, "source": "profiles/%s/workloads_pmc_summary.json" % wl_round}
+                per = lambda cyc: sq["SQ_INSTS_VALU"] * cyc / (1024 * ghz * 1e9) * 1e3
+                return {"valu_wave_insts_per_call": sq["SQ_INSTS_VALU"], "clock_ghz": ghz, "clock_measured": last_clock[0] is not None,
+                        "issue_ms_if_every_inst_were_fast": per(VALU_FAST_CYCLES), "issue_ms_if_every_inst_were_slow": per(VALU_SLOW_CYCLES),
+                        "measured_ms": ms, "measured_over_fast_bound": ms / per(VALU_FAST_CYCLES),
+                        "cycles_per_wave_inst": {"fast": VALU_FAST_CYCLES, "slow": VALU_SLOW_CYCLES},
+                        "source": "profiles/%s/workloads_pmc_summary.json (SQ_INSTS_VALU)" % wl_round}
 
             def roof(alg_bytes, ms, kernels_us, what, key=None):
                 gbs = alg_bytes / (ms * 1e-3) / 1e9
@@ -718,9 +729,10 @@ def main():
                 "rp64_permutations_per_s": perms / (hash_ms * 1e-3), "sclk_mhz_under_load": last_clock[0],
                 "valu": issue("lde_commit_2^20x4_b8_f64_rp64", ms_r),
                 "what": "Rp64_256: one permutation per row (4 elements < rate 8) + one per Merkle merge.  The bound is VALU issue: `valu` "
-                        "is the issue floor of the whole call from its counter run (SQ_ACTIVE_INST_VALU x 4 cycles over 1024 SIMDs at the "
-                        "measured clock) and the fraction of the kernel time it accounts for.  (Round 3 quoted a 'modmul ceiling' fraction "
-                        "of 1.05: 6384 products per permutation priced the shift-only MDS layers as products — not a ceiling, dropped.)"}
+                        "brackets the issue time of the whole call from its counter run (SQ_INSTS_VALU at the fast and at the slow class's "
+                        "issue rate, 1024 SIMDs at the measured clock): the kernel time must lie above the first and lies below the second "
+                        "when a good part of the stream is plain 32-bit arithmetic.  (Round 3 quoted a 'modmul ceiling' fraction of 1.05, "
+                        "the first half of round 4 'insts x 4 cycles' with a fraction of 1.2: neither was a ceiling, both dropped.)"}
             ex["rp64_permutations_per_s"] = rl["lde_commit_2^20x4_b8_f64_rp64"]["rp64_permutations_per_s"]
             del cm_r
             lv = ctx.to_device(rng.integers(0, 256, (1 << 23, 32), dtype=np.uint8))

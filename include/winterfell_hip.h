@@ -248,6 +248,20 @@ int wf_coin_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_
 int wf_coin_reseed_draw(wf_ctx *ctx, int hash, int field, uint32_t ext_degree, void *d_coin, const void *d_digest, void *d_digest_copy,
                         void *d_out);
 int wf_coin_read(wf_ctx *ctx, const void *d_coin, void *h_seed, uint64_t *h_counter);
+/* The query phase's two coin steps against the device coin (round 4: with them Prover::generate_proof, prover/src/lib.rs:282-492, has
+ * no host round trip between the first commitment and the query positions):
+ *   wf_coin_grind          ProverChannel::grind_query_seed (prover/src/channel.rs:169-185): *d_nonce := the smallest nonce in
+ *                          [1, 2^log_max_tries] with check_leading_zeros(nonce) >= grinding_factor for the coin's CURRENT seed (the coin
+ *                          is not changed); a fixed queue of batches in increasing order, each returning at once when an earlier one
+ *                          has found a nonce, so nothing is read back in between.  No nonce in the range: the coin's failed flag
+ *                          (wf_coin_read: WF_ERR_NOT_FOUND).  log_max_tries <= grinding_factor + 12 keeps the queue short; the search
+ *                          fails with probability exp(-2^(log_max_tries - grinding_factor)).
+ *   wf_coin_draw_integers  RandomCoin::draw_integers (crypto/src/random/default.rs:209-248): seed := merge_with_int(seed, *d_nonce),
+ *                          counter := 0, d_out[i] := the first 8 bytes of next(), little-endian, masked to 2^log_domain_size, for
+ *                          i < num_values <= 256 (duplicates are removed by the caller, prover/src/channel.rs:156-165). */
+int wf_coin_grind(wf_ctx *ctx, int hash, const void *d_coin, uint32_t grinding_factor, uint32_t log_max_tries, void *d_nonce /* uint64 */);
+int wf_coin_draw_integers(wf_ctx *ctx, int hash, void *d_coin, const void *d_nonce, uint32_t num_values, uint32_t log_domain_size,
+                          void *d_out /* num_values x uint64 */);
 
 /* ElementHasher::hash_elements over `count` independent rows (hash/mod.rs:56-64); same layout as wf_hash_rows
  * without partitions. */
@@ -324,6 +338,18 @@ int wf_evaluate_constraints_assertions(wf_ctx *ctx, int air, int field, uint32_t
                                        const uint64_t *h_assert_num_values, const void *h_assert_values, const void *h_cc_boundary,
                                        void *d_out);
 
+/* wf_evaluate_constraints_assertions with the composition coefficients in DEVICE memory, in the order the coin draws them
+ * (ProverChannel::get_constraint_composition_coeffs, prover/src/channel.rs:126-138; air/src/air/mod.rs:529-560): d_cc_transition =
+ * num_transition_constraints elements, d_cc_boundary = one element per assertion, assertion k of the h_assert_* arrays taking
+ * coefficient k.  h_assert_strides / h_assert_num_values may both be NULL (every assertion single-valued).  The small tables of the
+ * call are uploaded through page-locked slots of the context: nothing waits for the stream. */
+int wf_evaluate_constraints_dev(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                const void *d_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                const uint64_t *h_assert_first_steps, const uint64_t *h_assert_strides,
+                                const uint64_t *h_assert_num_values, const void *h_assert_values, const void *d_cc_boundary,
+                                void *d_out);
+
 /* The same for a trace with an auxiliary segment (TraceInfo::is_multi_segment): evaluate_fragment_full
  * (evaluator/default.rs:214-271) = the main transition constraints as above plus Air::evaluate_aux_transition over the
  * main frame, the auxiliary frame (rows of the device-resident row-major LDE of the aux segment: aux_row_width base
@@ -352,6 +378,12 @@ int wf_polys_evaluate_at(wf_ctx *ctx, int field, uint32_t poly_ext_degree, uint3
                          uint32_t num_cols, uint64_t col_stride, uint32_t log_n, const void *h_points,
                          uint32_t num_points, void *h_out);
 
+/* get_ood_frame with the point in DEVICE memory (d_point: one element of ext_degree words, where wf_coin_draw put it) and the values
+ * left on the device: d_out[p][col] for p = 0 (at the point) and, with_next != 0, p = 1 (at point * g, g = the generator of the
+ * 2^log_n domain).  Nothing waits for the stream. */
+int wf_polys_evaluate_at_dev(wf_ctx *ctx, int field, uint32_t poly_ext_degree, uint32_t ext_degree, const void *d_polys,
+                             uint32_t num_cols, uint64_t col_stride, uint32_t log_n, const void *d_point, int with_next, void *d_out);
+
 /* DeepCompositionPoly::add_trace_polys (prover/src/composer/mod.rs:67-169): the coefficients of
  *   sum_i cc_i * [ (T_i(x) - T_i(z)) / (x - z) + (T_i(x) - T_i(z*g)) / (x - z*g) ]
  * over the main-segment polys (base field), the aux-segment polys and the composition-poly columns (both over the
@@ -365,6 +397,13 @@ int wf_deep_compose(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_m
                     uint64_t main_stride, const void *d_aux_polys, uint32_t num_aux, uint64_t aux_stride,
                     const void *d_quotient_polys, uint32_t num_quotient, uint64_t quotient_stride, uint32_t log_n,
                     const void *h_z, const void *h_cc_trace, const void *h_cc_constraints, void *d_out);
+
+/* wf_deep_compose with z and the coefficients in DEVICE memory: d_cc = num_main + num_aux + num_quotient elements, trace columns first
+ * (DeepCompositionCoefficients {trace, constraints} in draw order, air/src/air/coefficients.rs:201-206). */
+int wf_deep_compose_dev(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_main_polys, uint32_t num_main,
+                        uint64_t main_stride, const void *d_aux_polys, uint32_t num_aux, uint64_t aux_stride,
+                        const void *d_quotient_polys, uint32_t num_quotient, uint64_t quotient_stride, uint32_t log_n,
+                        const void *d_z, const void *d_cc, void *d_out);
 
 /* ---- fri::FriProver (commit phase) ------------------------------------------------------------------- */
 /* FriProver::build_layer, first half (fri/src/prover/mod.rs:202-211): transpose_slice::<E, N> (utils/core/src/lib.rs:

@@ -152,7 +152,24 @@ def test_rescue_example_at_full_size(oracle):
         tm["total_with_serialisation"] = (time.perf_counter() - t0) * 1e3
         if best is None or tm["total_with_serialisation"] < best["total_with_serialisation"]:
             best = tm
-    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r03")
+    out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "r04")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, "rescue_prove_2^20_timings_ms.json"), "w") as fh:
         json.dump({k: round(v, 3) for k, v in best.items()}, fh, indent=1)
+    # round 4: the same proof with the coin on the device for the whole transcript (prove_device_transcript): byte for byte the
+    # proof above, and its timings next to it — how long the host takes to QUEUE the whole transcript, the one wait, the openings
+    host_bytes = pr.to_bytes()
+    best_dev = None
+    for _ in range(3):
+        tm = {}
+        ctx.sync()
+        t0 = time.perf_counter()
+        pd = prover.prove(air, d_trace, options, crypto.Blake3_256, ex["pub"], timings=tm, transcript="device")
+        dev_bytes = pd.to_bytes()
+        ctx.sync()
+        tm["total_with_serialisation"] = (time.perf_counter() - t0) * 1e3
+        assert "queue_whole_transcript" in tm and dev_bytes == host_bytes
+        if best_dev is None or tm["total_with_serialisation"] < best_dev["total_with_serialisation"]:
+            best_dev = tm
+    with open(os.path.join(out, "rescue_prove_2^20_device_transcript_timings_ms.json"), "w") as fh:
+        json.dump({k: round(v, 3) for k, v in best_dev.items()}, fh, indent=1)

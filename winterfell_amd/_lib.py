@@ -86,6 +86,11 @@ _PROTOS = {
     "wf_comm_sharded_commit": [_vp, _int, _int, _u32, _vp, _u32, _u64, _u32, _u32, _vp, _int, _vp, _vp, _vp, _vp, _vp],
     "wf_comm_sharded_fri_layers": [_vp, _int, _int, _u32, _vp, _u32, _u32, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "wf_fri_apply_drp_rows_dev": [_vp, _int, _u32, _vp, _u32, _u32, _u64, _u64, _vp, _vp, _vp],
+    "wf_coin_grind": [_vp, _int, _vp, _u32, _u32, _vp],
+    "wf_coin_draw_integers": [_vp, _int, _vp, _vp, _u32, _u32, _vp],
+    "wf_evaluate_constraints_dev": [_vp, _int, _int, _u32, _vp, _u64, _u32, _u32, _u32, _vp, _vp, _u32, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
+    "wf_polys_evaluate_at_dev": [_vp, _int, _u32, _u32, _vp, _u32, _u64, _u32, _vp, _int, _vp],
+    "wf_deep_compose_dev": [_vp, _int, _u32, _vp, _u32, _u64, _vp, _u32, _u64, _vp, _u32, _u64, _u32, _vp, _vp, _vp],
 }
 
 _lib = None

@@ -119,7 +119,110 @@ int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t 
 }
 
 
+// ProverChannel::grind_query_seed (prover/src/channel.rs:169-185) against the device coin: lanes test nonces first + gid with the seed
+// READ FROM THE COIN; the minimum of the passing nonces goes to *best.  Launched as a fixed sequence of batches in increasing
+// nonce order: a batch returns at once when an earlier one has found a nonce (stream order makes *best final by then), so the
+// result is the serial reference's answer — the smallest nonce — and nothing comes back to the host between the batches.
+template <class H>
+__global__ __launch_bounds__(256) void coin_grind_kernel(const CoinState *c, uint64_t first, uint64_t count, uint32_t factor,
+                                                         unsigned long long *best) {
+    if (*(volatile unsigned long long *)best != ~0ull && *(volatile unsigned long long *)best < first) return;
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid >= count) return;
+    uint32_t seed[8], d[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) seed[i] = c->seed[i];
+    H::merge_with_int(seed, first + gid, d);
+    const uint64_t h = H::head(d);
+    const uint32_t tz = h ? (uint32_t)__builtin_ctzll(h) : 64u;
+    if (tz >= factor) atomicMin(best, (unsigned long long)(first + gid));
+}
+
+// no nonce in the searched range: the coin's failed flag (wf_coin_read -> WF_ERR_NOT_FOUND)
+__global__ void coin_grind_check_kernel(CoinState *c, const unsigned long long *best) {
+    if (*best == ~0ull) c->failed = 1;
+}
+
+// RandomCoin::draw_integers (crypto/src/random/default.rs:209-248): seed = merge_with_int(seed, nonce), counter = 0, then
+// value i = the first 8 bytes (little-endian) of next() = merge_with_int(seed, i + 1), masked to the domain.  The values are
+// independent given the new seed: one lane each.  The counter ends at num_values, as after the reference's loop.
+template <class H>
+__global__ __launch_bounds__(256) void coin_draw_integers_kernel(CoinState *c, const unsigned long long *nonce, uint32_t num_values, uint64_t mask,
+                                                                 uint64_t *out) {
+    __shared__ uint32_t ns[8];
+    if (threadIdx.x == 0) {
+        uint32_t seed[8], d[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) seed[i] = c->seed[i];
+        H::merge_with_int(seed, (uint64_t)*nonce, d);
+#pragma unroll
+        for (int i = 0; i < 8; i++) ns[i] = d[i];
+    }
+    __syncthreads();
+    uint32_t seed[8], d[8], b[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) seed[i] = ns[i];
+    if (threadIdx.x < num_values) {
+        H::merge_with_int(seed, (uint64_t)threadIdx.x + 1, d);
+        H::as_bytes(d, b);
+        out[threadIdx.x] = ((uint64_t)b[0] | ((uint64_t)b[1] << 32)) & mask;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) c->seed[i] = ns[i];
+        c->counter = num_values;
+    }
+}
+
 }  // namespace
+
+extern "C" int wf_coin_grind(wf_ctx *ctx, int hash, const void *d_coin, uint32_t grinding_factor, uint32_t log_max_tries, void *d_nonce) {
+    WF_ENTER(ctx);
+    if (!ctx || !d_coin || !d_nonce || grinding_factor > 32 || log_max_tries > 40) return WF_ERR_INVALID_ARG;
+    WF_TRY(check_hash(hash));
+    // nonces 1 .. 2^log_max_tries in batches of up to 2^22 lanes (Rescue: 2^20), every batch behind the early-out of the kernel
+    uint32_t lg = grinding_factor + 1;
+    if (lg < 16) lg = 16;
+    if (lg > 22) lg = 22;
+    if ((hash == WF_HASH_RP64_256 || hash == WF_HASH_RPJIVE64_256 || hash == WF_HASH_RP62_248) && lg > 20) lg = 20;
+    if (lg > log_max_tries) lg = log_max_tries;
+    const uint64_t batch = 1ull << lg, total = 1ull << log_max_tries;
+    if (total / batch > 4096) return WF_ERR_INVALID_ARG;                 // a queue of launches, not a search loop: bound it
+    unsigned long long *best = (unsigned long long *)d_nonce;
+    WF_HIP(hipMemsetAsync(best, 0xff, 8, ctx->stream));
+    return with_hasher(hash, [&](auto h) -> int {
+        typedef decltype(h) H;
+        wf_prof_begin(ctx, H::grind_name());
+        for (uint64_t first = 1; first <= total; first += batch) {
+            const uint64_t count = total - first + 1 < batch ? total - first + 1 : batch;
+            hipLaunchKernelGGL(coin_grind_kernel<H>, dim3((uint32_t)((count + 255) / 256)), dim3(256), 0, ctx->stream, (const CoinState *)d_coin, first,
+                               count, grinding_factor, best);
+        }
+        hipLaunchKernelGGL(coin_grind_check_kernel, dim3(1), dim3(1), 0, ctx->stream, (CoinState *)d_coin, (const unsigned long long *)best);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+        return (int)WF_OK;
+    });
+}
+
+extern "C" int wf_coin_draw_integers(wf_ctx *ctx, int hash, void *d_coin, const void *d_nonce, uint32_t num_values, uint32_t log_domain_size,
+                                     void *d_out) {
+    WF_ENTER(ctx);
+    if (!ctx || !d_coin || !d_nonce || !d_out || num_values == 0 || num_values > 256 || log_domain_size == 0 || log_domain_size > 63)
+        return WF_ERR_INVALID_ARG;
+    if ((uint64_t)num_values >= (1ull << log_domain_size)) return WF_ERR_INVALID_ARG;      // "number of values must be smaller than domain size"
+    WF_TRY(check_hash(hash));
+    wf_prof_begin(ctx, "coin");
+    WF_TRY(with_hasher(hash, [&](auto h) {
+        hipLaunchKernelGGL(coin_draw_integers_kernel<decltype(h)>, dim3(1), dim3(256), 0, ctx->stream, (CoinState *)d_coin,
+                           (const unsigned long long *)d_nonce, num_values, (1ull << log_domain_size) - 1, (uint64_t *)d_out);
+        return (int)WF_OK;
+    }));
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
 
 extern "C" int wf_coin_init(wf_ctx *ctx, void *d_coin, const void *h_seed) {
     WF_ENTER(ctx);

@@ -460,6 +460,8 @@ struct AuxArgs {
 // and the number of values; h_vals then holds all values back to back.  Null pointers: every assertion is Assertion::single.
 struct MultiArgs {
     const uint64_t *h_strides = nullptr, *h_nvals = nullptr;
+    // composition coefficients already on the device (wf_evaluate_constraints_dev: where wf_coin_draw put them) instead of h_cc_*
+    const void *d_cc_t = nullptr, *d_cc_b = nullptr;
 };
 
 // pool blocks that go back to the context's pool on every way out (stream-ordered: safe right after the launches that use them)
@@ -578,10 +580,14 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
         for (auto *vec : {&x_val, &cc_x, &rnd})
             for (auto &v : *vec) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
     }
-    memcpy((void *)cc_b.data(), h_cc_b, cc_b.size() * sizeof(T));
-    memcpy((void *)cc_t.data(), h_cc_t, cc_t.size() * sizeof(T));
-    for (auto &v : cc_b) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
-    for (auto &v : cc_t) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+    const bool dev_cc = multi.d_cc_t != nullptr;      // the coefficients never visit the host (a device coin drew them: canonical words)
+    if (dev_cc != (multi.d_cc_b != nullptr) || (!dev_cc && (!h_cc_b || !h_cc_t))) return WF_ERR_INVALID_ARG;
+    if (!dev_cc) {
+        memcpy((void *)cc_b.data(), h_cc_b, cc_b.size() * sizeof(T));
+        memcpy((void *)cc_t.data(), h_cc_t, cc_t.size() * sizeof(T));
+        for (auto &v : cc_b) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+        for (auto &v : cc_t) { if (!HF::valid_internal(v)) return WF_ERR_INVALID_ARG; v = HF::to_internal(HF::from_internal(v)); }
+    }
 
     // transition divisor: inverse of x^n - 1 over its ce_blowup distinct values (get_inv_evaluation), exemption g^(n-1)
     std::vector<T> zt(ce_blowup);
@@ -664,7 +670,9 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
         up(d_xcol, x_col.data(), x_col.size() * sizeof(uint32_t));
         up(d_xgrp, x_group.data(), x_group.size() * sizeof(uint32_t));
     }
-    WF_TRY(batch.flush());                         // synchronises: the host vectors die with this frame
+    // the host vectors die with this frame: flush() waits for the stream; with the coefficients on the device the caller is queueing
+    // a chain (prove() against a device coin), so the image goes through a page-locked slot of the context and nothing waits
+    WF_TRY(dev_cc ? batch.flush_async() : batch.flush());
 
     SeriesTable xs;
     WF_TRY(wf_get_series_table<HF>(ctx, g_ce, off, log_ce, &xs));
@@ -693,7 +701,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.exempt = exempt;
     p.exempt2 = HF::to_internal(HF::powmod(g_trace, n - 2));
     p.zb = d_zb;
-    p.cc_t = d_cct;
+    p.cc_t = dev_cc ? (const T *)multi.d_cc_t : d_cct;
     p.num_assert = num_assert;
     p.ngroups = ngroups;
     p.a_col = d_acol;
@@ -701,7 +709,7 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
     p.a_val = d_aval;
     p.a_seq = d_aseq;
     p.seq = d_seq;
-    p.cc_b = d_ccb;
+    p.cc_b = dev_cc ? (const T *)multi.d_cc_b : d_ccb;
     p.aux_lde = (const T *)aux.d_lde;
     p.aux_row_width = aux.row_width;
     p.rand = d_rnd;
@@ -794,6 +802,25 @@ extern "C" int wf_evaluate_constraints_assertions(wf_ctx *ctx, int air, int fiel
     return evaluate_single_segment(ctx, air, field, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,
                                    h_cc_transition, num_assertions, h_assert_columns, h_assert_first_steps, h_assert_values, h_cc_boundary, d_out,
                                    multi);
+}
+
+extern "C" int wf_evaluate_constraints_dev(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
+                                          uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
+                                          const void *d_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,
+                                          const uint64_t *h_assert_first_steps, const uint64_t *h_assert_strides,
+                                          const uint64_t *h_assert_num_values, const void *h_assert_values, const void *d_cc_boundary,
+                                          void *d_out) {
+    WF_ENTER(ctx);
+    if (!d_trace_lde || !h_domain_offset || !d_cc_transition || !h_assert_columns || !h_assert_first_steps || !h_assert_values ||
+        !d_cc_boundary || !d_out || ((h_assert_strides == nullptr) != (h_assert_num_values == nullptr)))
+        return WF_ERR_INVALID_ARG;
+    MultiArgs multi;
+    multi.h_strides = h_assert_strides;
+    multi.h_nvals = h_assert_num_values;
+    multi.d_cc_t = d_cc_transition;
+    multi.d_cc_b = d_cc_boundary;
+    return evaluate_single_segment(ctx, air, field, ext_degree, d_trace_lde, row_width, log_n, log_lde_blowup, log_ce_blowup, h_domain_offset,
+                                   nullptr, num_assertions, h_assert_columns, h_assert_first_steps, h_assert_values, nullptr, d_out, multi);
 }
 
 extern "C" int wf_evaluate_constraints_aux(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_main_lde, uint64_t main_row_width,

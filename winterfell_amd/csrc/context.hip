@@ -269,6 +269,23 @@ int wf_copy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     return WF_OK;
 }
 
+int wf_copy_h2d_small_async(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
+    if (bytes == 0) return WF_OK;
+    if (bytes > wf_ctx::STAGE_BYTES) return wf_copy_h2d(ctx, d_dst, h_src, bytes);
+    const uint32_t i = ctx->stage_next;
+    ctx->stage_next = (i + 1) % wf_ctx::STAGE_SLOTS;
+    if (!ctx->h_stage[i]) {
+        WF_HIP(hipHostMalloc(&ctx->h_stage[i], wf_ctx::STAGE_BYTES, hipHostMallocDefault));
+        WF_HIP(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+    }
+    if (ctx->stage_busy[i]) WF_HIP(hipEventSynchronize(ctx->stage_ev[i]));   // the copy that last read this slot (eight uploads ago)
+    memcpy(ctx->h_stage[i], h_src, bytes);
+    WF_HIP(hipMemcpyAsync(d_dst, ctx->h_stage[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+    WF_HIP(hipEventRecord(ctx->stage_ev[i], ctx->stream));
+    ctx->stage_busy[i] = true;
+    return WF_OK;
+}
+
 int wf_copy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
     if (bytes == 0) {
         WF_HIP(hipStreamSynchronize(ctx->stream));
@@ -392,6 +409,10 @@ extern "C" int wf_ctx_destroy(wf_ctx *ctx) {
     for (int i = 0; i < 2; i++) {
         if (ctx->h_bounce[i]) (void)hipHostFree(ctx->h_bounce[i]);
         if (ctx->bounce_ev[i]) (void)hipEventDestroy(ctx->bounce_ev[i]);
+    }
+    for (int i = 0; i < wf_ctx::STAGE_SLOTS; i++) {
+        if (ctx->h_stage[i]) (void)hipHostFree(ctx->h_stage[i]);
+        if (ctx->stage_ev[i]) (void)hipEventDestroy(ctx->stage_ev[i]);
     }
     if (ctx->h_status) (void)hipHostFree(ctx->h_status);
     for (auto &r : ctx->prof) {

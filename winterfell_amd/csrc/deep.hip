@@ -96,6 +96,18 @@ __global__ __launch_bounds__(256) void pows_kernel(Elems4<typename F::T, D> base
     for (int d = 0; d < D; d++) out[(NPOW + t) * D + d] = acc[d];
 }
 
+// out = [z, z * g] (g a base-field element in internal form: coordinate-wise), z read from DEVICE memory — the out-of-domain point
+// where a device coin drew it (wf_polys_evaluate_at_dev / wf_deep_compose_dev)
+template <class F, int D>
+__global__ void ood_points_kernel(const typename F::T *z, typename F::T g, typename F::T *out) {
+    const int d = threadIdx.x;
+    if (d < D) {
+        const typename F::T v = F::load_norm(z[d]);
+        out[d] = v;
+        out[D + d] = F::mul(v, g);
+    }
+}
+
 // workgroup sum of one degree-D element per lane; result valid in lane 0
 template <class F, int D>
 __device__ __forceinline__ void block_sum(typename F::T (&v)[D], typename F::T (*buf)[D]) {
@@ -437,6 +449,48 @@ struct Deep {
         for (int d = 0; d < D; d++) o[d] = HF::to_internal(HF::mulmod(HF::from_internal(z[d]), g_canon));
     }
 
+    // the same with the point in device memory (d_point: one element; with_next: also at d_point * g, g = the generator of the 2^log_n
+    // domain — the frame {z, z g} of get_ood_frame) and the values left on the device: d_out[num_points][num_cols] elements.
+    // Nothing waits for the stream.
+    template <int PD>
+    static int evaluate_at_dev(wf_ctx *ctx, const void *d_polys, uint32_t num_cols, uint64_t col_stride, uint32_t log_n,
+                               const void *d_point, bool with_next, void *d_out_user) {
+        const uint32_t num_points = with_next ? 2 : 1;
+        const uint32_t log_thr = log_n < 8 ? log_n : 8;
+        uint32_t log_seg = log_n;
+        while (log_seg > 10 && log_n - log_seg < 10 && ((uint64_t)num_cols << (log_n - log_seg)) < 4096) log_seg--;
+        if (log_seg < log_thr) log_seg = log_thr;
+        const uint32_t nseg = 1u << (log_n - log_seg);
+        void *tmp;
+        const size_t words = (size_t)num_points * PW_WORDS + (size_t)num_points * num_cols * nseg * D + 2 * D;
+        WF_TRY(wf_scratch(ctx, 1, words * sizeof(T), &tmp));
+        T *pw = (T *)tmp, *partials = pw + (size_t)num_points * PW_WORDS, *pts = partials + (size_t)num_points * num_cols * nseg * D;
+        T *d_out = (T *)d_out_user;
+        hipLaunchKernelGGL((ood_points_kernel<F, D>), dim3(1), dim3(64), 0, ctx->stream, (const T *)d_point,
+                           HF::to_internal(HF::root_of_unity(log_n)), pts);
+        WF_HIP(hipGetLastError());
+        for (uint32_t g = 0; g < num_points; g++) WF_TRY(make_pows(ctx, nullptr, pts, (int)g, pw + g * PW_WORDS));
+        const T *polys = (const T *)d_polys;
+        wf_prof_begin(ctx, "poly_eval_at");
+        const dim3 grid(nseg, num_cols), block(256);
+        if (num_points == 2)
+            hipLaunchKernelGGL((eval_partial_kernel<F, PD, D, 2>), grid, block, 0, ctx->stream, polys, col_stride, log_seg, log_thr, (const T *)pw,
+                               (uint64_t)PW_WORDS, partials);
+        else
+            hipLaunchKernelGGL((eval_partial_kernel<F, PD, D, 1>), grid, block, 0, ctx->stream, polys, col_stride, log_seg, log_thr, (const T *)pw,
+                               (uint64_t)PW_WORDS, partials);
+        const uint32_t total = num_points * num_cols;
+        if (nseg > 16)
+            hipLaunchKernelGGL((eval_combine_wide_kernel<F, D>), dim3(total), dim3(256), 0, ctx->stream, (const T *)partials, num_cols,
+                               log_n - log_seg, log_seg, (const T *)pw, (uint64_t)PW_WORDS, HF::to_internal(HF::from_u64(1)), d_out);
+        else
+            hipLaunchKernelGGL((eval_combine_kernel<F, D>), dim3((total + 63) / 64), dim3(64), 0, ctx->stream, (const T *)partials, num_cols, nseg,
+                               log_seg, num_points, (const T *)pw, (uint64_t)PW_WORDS, d_out);
+        wf_prof_end(ctx);
+        WF_HIP(hipGetLastError());
+        return WF_OK;
+    }
+
     template <int PD>
     static int evaluate_at(wf_ctx *ctx, const void *d_polys, uint32_t num_cols, uint64_t col_stride, uint32_t log_n,
                            const void *h_points, uint32_t num_points, void *h_out) {
@@ -491,27 +545,43 @@ struct Deep {
 
     static int compose(wf_ctx *ctx, const void *d_main, uint32_t c_main, uint64_t main_stride, const void *d_aux, uint32_t c_aux,
                        uint64_t aux_stride, const void *d_quot, uint32_t c_q, uint64_t q_stride, uint32_t log_n, const void *h_z,
-                       const void *h_cc_trace, const void *h_cc_constraints, void *d_out) {
+                       const void *h_cc_trace, const void *h_cc_constraints, void *d_out, const void *d_z = nullptr,
+                       const void *d_cc_all = nullptr) {
+        // d_z / d_cc_all: the point and the c_main + c_aux + c_q coefficients (trace columns first) in DEVICE memory, where a device
+        // coin drew them (wf_deep_compose_dev): nothing is copied and nothing waits for the stream
         const uint64_t n = 1ull << log_n;
         const uint32_t c_total = c_main + c_aux + c_q;
+        const bool dev = d_z != nullptr;
         T z[D], zg[D];
-        WF_TRY(load_elem(h_z, 0, z));
-        mul_base(z, HF::root_of_unity(log_n), zg);
-        std::vector<T> cc((size_t)c_total * D);
-        for (uint32_t i = 0; i < c_total; i++) {
-            T e[D];
-            WF_TRY(i < c_main + c_aux ? load_elem(h_cc_trace, i, e) : load_elem(h_cc_constraints, i - c_main - c_aux, e));
-            for (int d = 0; d < D; d++) cc[(size_t)i * D + d] = e[d];
+        std::vector<T> cc(dev ? 0 : (size_t)c_total * D);
+        if (!dev) {
+            WF_TRY(load_elem(h_z, 0, z));
+            mul_base(z, HF::root_of_unity(log_n), zg);
+            for (uint32_t i = 0; i < c_total; i++) {
+                T e[D];
+                WF_TRY(i < c_main + c_aux ? load_elem(h_cc_trace, i, e) : load_elem(h_cc_constraints, i - c_main - c_aux, e));
+                for (int d = 0; d < D; d++) cc[(size_t)i * D + d] = e[d];
+            }
         }
         void *tmp0, *tmp1;
-        const size_t small_words = 2 * PW_WORDS + cc.size() + syndiv_words(log_n);
+        const size_t cc_words = (size_t)c_total * D;
+        const size_t small_words = 2 * PW_WORDS + cc_words + 2 * D + syndiv_words(log_n);
         WF_TRY(wf_scratch(ctx, 0, (size_t)n * D * sizeof(T), &tmp0));
         WF_TRY(wf_scratch(ctx, 1, small_words * sizeof(T), &tmp1));
         T *S = (T *)tmp0;
-        T *pw_z = (T *)tmp1, *pw_zg = pw_z + PW_WORDS, *d_cc = pw_zg + PW_WORDS, *rest = d_cc + cc.size();
-        WF_TRY(wf_copy_h2d(ctx, d_cc, cc.data(), cc.size() * sizeof(T)));   // synchronises: cc is a stack-lifetime host buffer
-        WF_TRY(make_pows(ctx, z, nullptr, 0, pw_z));
-        WF_TRY(make_pows(ctx, zg, nullptr, 0, pw_zg));
+        T *pw_z = (T *)tmp1, *pw_zg = pw_z + PW_WORDS, *d_cc = pw_zg + PW_WORDS, *pts = d_cc + cc_words, *rest = pts + 2 * D;
+        if (dev) {
+            hipLaunchKernelGGL((ood_points_kernel<F, D>), dim3(1), dim3(64), 0, ctx->stream, (const T *)d_z,
+                               HF::to_internal(HF::root_of_unity(log_n)), pts);
+            WF_HIP(hipGetLastError());
+            WF_TRY(make_pows(ctx, nullptr, pts, 0, pw_z));
+            WF_TRY(make_pows(ctx, nullptr, pts, 1, pw_zg));
+            d_cc = (T *)d_cc_all;
+        } else {
+            WF_TRY(wf_copy_h2d(ctx, d_cc, cc.data(), cc.size() * sizeof(T)));   // synchronises: cc is a stack-lifetime host buffer
+            WF_TRY(make_pows(ctx, z, nullptr, 0, pw_z));
+            WF_TRY(make_pows(ctx, zg, nullptr, 0, pw_zg));
+        }
         wf_prof_begin(ctx, "deep_acc");
         hipLaunchKernelGGL((deep_acc_kernel<F, D>), dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, ctx->stream, (const T *)d_main, c_main,
                            main_stride, (const T *)d_aux, c_aux, aux_stride, (const T *)d_quot, c_q, q_stride, n, (const T *)d_cc, S);
@@ -536,6 +606,39 @@ int evaluate_at_dispatch(wf_ctx *ctx, uint32_t pD, uint32_t D, const void *d_pol
     if constexpr (HF::Dev::MAX_EXT >= 3)
         return pD == 1 ? Deep<HF, 3>::template evaluate_at<1>(ctx, d_polys, num_cols, col_stride, log_n, h_points, num_points, h_out)
                        : Deep<HF, 3>::template evaluate_at<3>(ctx, d_polys, num_cols, col_stride, log_n, h_points, num_points, h_out);
+    return WF_ERR_UNSUPPORTED;
+}
+
+template <class HF>
+int evaluate_at_dev_dispatch(wf_ctx *ctx, uint32_t pD, uint32_t D, const void *d_polys, uint32_t num_cols, uint64_t col_stride, uint32_t log_n,
+                             const void *d_point, bool with_next, void *d_out) {
+    if (D < 1 || D > (uint32_t)HF::Dev::MAX_EXT || (pD != 1 && pD != D)) return WF_ERR_UNSUPPORTED;
+    if (log_n > HF::TWO_ADICITY || log_n > 32) return WF_ERR_DOMAIN_TOO_LARGE;
+    if (D == 1) return Deep<HF, 1>::template evaluate_at_dev<1>(ctx, d_polys, num_cols, col_stride, log_n, d_point, with_next, d_out);
+    if (D == 2)
+        return pD == 1 ? Deep<HF, 2>::template evaluate_at_dev<1>(ctx, d_polys, num_cols, col_stride, log_n, d_point, with_next, d_out)
+                       : Deep<HF, 2>::template evaluate_at_dev<2>(ctx, d_polys, num_cols, col_stride, log_n, d_point, with_next, d_out);
+    if constexpr (HF::Dev::MAX_EXT >= 3)
+        return pD == 1 ? Deep<HF, 3>::template evaluate_at_dev<1>(ctx, d_polys, num_cols, col_stride, log_n, d_point, with_next, d_out)
+                       : Deep<HF, 3>::template evaluate_at_dev<3>(ctx, d_polys, num_cols, col_stride, log_n, d_point, with_next, d_out);
+    return WF_ERR_UNSUPPORTED;
+}
+
+template <class HF>
+int compose_dev_dispatch(wf_ctx *ctx, uint32_t D, const void *d_main, uint32_t c_main, uint64_t main_stride, const void *d_aux, uint32_t c_aux,
+                         uint64_t aux_stride, const void *d_quot, uint32_t c_q, uint64_t q_stride, uint32_t log_n, const void *d_z,
+                         const void *d_cc, void *d_out) {
+    if (D < 1 || D > (uint32_t)HF::Dev::MAX_EXT) return WF_ERR_UNSUPPORTED;
+    if (log_n > HF::TWO_ADICITY || log_n > 32) return WF_ERR_DOMAIN_TOO_LARGE;
+    if (D == 1)
+        return Deep<HF, 1>::compose(ctx, d_main, c_main, main_stride, d_aux, c_aux, aux_stride, d_quot, c_q, q_stride, log_n, nullptr, nullptr,
+                                    nullptr, d_out, d_z, d_cc);
+    if (D == 2)
+        return Deep<HF, 2>::compose(ctx, d_main, c_main, main_stride, d_aux, c_aux, aux_stride, d_quot, c_q, q_stride, log_n, nullptr, nullptr,
+                                    nullptr, d_out, d_z, d_cc);
+    if constexpr (HF::Dev::MAX_EXT >= 3)
+        return Deep<HF, 3>::compose(ctx, d_main, c_main, main_stride, d_aux, c_aux, aux_stride, d_quot, c_q, q_stride, log_n, nullptr, nullptr,
+                                    nullptr, d_out, d_z, d_cc);
     return WF_ERR_UNSUPPORTED;
 }
 
@@ -590,6 +693,36 @@ extern "C" int wf_deep_compose(wf_ctx *ctx, int field, uint32_t ext_degree, cons
         case WF_FIELD_F64: return compose_dispatch<HostF64>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, h_z, h_cc_trace, h_cc_constraints, d_out);
         case WF_FIELD_F128: return compose_dispatch<HostF128>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, h_z, h_cc_trace, h_cc_constraints, d_out);
         case WF_FIELD_F62: return compose_dispatch<HostF62>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, h_z, h_cc_trace, h_cc_constraints, d_out);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int wf_polys_evaluate_at_dev(wf_ctx *ctx, int field, uint32_t poly_ext_degree, uint32_t ext_degree, const void *d_polys,
+                                        uint32_t num_cols, uint64_t col_stride, uint32_t log_n, const void *d_point, int with_next,
+                                        void *d_out) {
+    WF_ENTER(ctx);
+    if (!ctx || !d_polys || !d_point || !d_out) return WF_ERR_INVALID_ARG;
+    if (num_cols == 0) return WF_OK;
+    if (col_stride < ((uint64_t)poly_ext_degree << log_n)) return WF_ERR_INVALID_ARG;
+    switch (field) {
+        case WF_FIELD_F64: return evaluate_at_dev_dispatch<HostF64>(ctx, poly_ext_degree, ext_degree, d_polys, num_cols, col_stride, log_n, d_point, with_next != 0, d_out);
+        case WF_FIELD_F128: return evaluate_at_dev_dispatch<HostF128>(ctx, poly_ext_degree, ext_degree, d_polys, num_cols, col_stride, log_n, d_point, with_next != 0, d_out);
+        case WF_FIELD_F62: return evaluate_at_dev_dispatch<HostF62>(ctx, poly_ext_degree, ext_degree, d_polys, num_cols, col_stride, log_n, d_point, with_next != 0, d_out);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+}
+
+extern "C" int wf_deep_compose_dev(wf_ctx *ctx, int field, uint32_t ext_degree, const void *d_main_polys, uint32_t num_main,
+                                   uint64_t main_stride, const void *d_aux_polys, uint32_t num_aux, uint64_t aux_stride,
+                                   const void *d_quotient_polys, uint32_t num_quotient, uint64_t quotient_stride, uint32_t log_n,
+                                   const void *d_z, const void *d_cc, void *d_out) {
+    WF_ENTER(ctx);
+    if (!ctx || !d_z || !d_cc || !d_out || log_n == 0) return WF_ERR_INVALID_ARG;
+    if ((num_main && !d_main_polys) || (num_aux && !d_aux_polys) || (num_quotient && !d_quotient_polys)) return WF_ERR_INVALID_ARG;
+    switch (field) {
+        case WF_FIELD_F64: return compose_dev_dispatch<HostF64>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, d_z, d_cc, d_out);
+        case WF_FIELD_F128: return compose_dev_dispatch<HostF128>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, d_z, d_cc, d_out);
+        case WF_FIELD_F62: return compose_dev_dispatch<HostF62>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, d_z, d_cc, d_out);
         default: return WF_ERR_UNSUPPORTED;
     }
 }

@@ -101,6 +101,14 @@ struct wf_ctx {
     // pinned bounce buffers for host <-> device copies of PAGEABLE caller memory (context.hip: staged_copy)
     void *h_bounce[2] = {nullptr, nullptr};
     hipEvent_t bounce_ev[2] = {nullptr, nullptr};
+    // small host -> device uploads that do NOT wait for the stream (wf_copy_h2d_small_async): a ring of page-locked slots, each
+    // reused only after the copy that last read it has completed (its event)
+    static constexpr int STAGE_SLOTS = 8;
+    static constexpr size_t STAGE_BYTES = 64u << 10;
+    void *h_stage[STAGE_SLOTS] = {};
+    hipEvent_t stage_ev[STAGE_SLOTS] = {};
+    bool stage_busy[STAGE_SLOTS] = {};
+    uint32_t stage_next = 0;
     // device status word (one uint32_t, zero = fine): kernels that detect a protocol failure (a Merkle ticket that can never
     // complete) set a bit; wf_ctx_sync and every synchronising entry point report it as WF_ERR_DEVICE_STATUS
     uint32_t *d_status = nullptr;
@@ -126,6 +134,9 @@ int wf_dev_free(wf_ctx *ctx, void *d_ptr);
 // host <-> device copies that never hand PAGEABLE caller memory to the runtime (see context.hip); synchronise the stream
 int wf_copy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wf_copy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes);
+// the same host -> device copy for at most wf_ctx::STAGE_BYTES, enqueued WITHOUT waiting for the stream: the bytes are copied into a
+// page-locked slot of the context first, so h_src may die as soon as the call returns (larger copies fall back to wf_copy_h2d)
+int wf_copy_h2d_small_async(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes);
 int wf_check_status(wf_ctx *ctx);    // after a stream synchronisation: WF_ERR_DEVICE_STATUS when a kernel flagged a failure
 
 // several small host -> device copies whose destinations lie in ONE device block: collected into a host image, flushed as one
@@ -142,6 +153,8 @@ struct WfUploadBatch {
         memcpy(&image[off], h_src, n);
     }
     int flush() { return image.empty() ? (int)WF_OK : wf_copy_h2d(ctx, d_base, image.data(), image.size()); }
+    // the same without waiting for the stream (images of at most wf_ctx::STAGE_BYTES; larger ones synchronise as flush() does)
+    int flush_async() { return image.empty() ? (int)WF_OK : wf_copy_h2d_small_async(ctx, d_base, image.data(), image.size()); }
 };
 
 #define WF_ENTER(ctx)                                   \

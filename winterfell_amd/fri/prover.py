@@ -93,7 +93,7 @@ class FriProver:
             ev, length = folded, rows
         self._set_remainder(channel, ev, length)
 
-    def _build_layers_fused(self, channel, coin, ev, length, off_p):
+    def _build_layers_fused(self, channel, coin, ev, length, off_p, defer=False):
         """the same loop AND the remainder step as one library call against a device-resident coin (wf_fri_build_layers): commit,
         reseed, draw, fold for every layer, then interpolate / reverse / hash / reseed for the remainder, are queued back to back;
         roots, alphas, the remainder and the coin come back in one read at the end"""
@@ -131,22 +131,32 @@ class FriProver:
         roots, alphas, rem, state = back[:o_alpha], back[o_alpha:o_rem], back[o_rem:o_coin], back[o_coin:]
         coin.move_to(state)
         arr = lambda ts: (ctypes.c_void_p * nl)(*[t.data_ptr() for t in ts])
-        try:
+        def queue():
             ctx.call("wf_fri_build_layers", self.hasher.HASH_ID, f.ID, D, ptr(ev), log_len, N, nl, off_p, ptr(coin.state), arr(tr), arr(lv), arr(nd),
                      arr(fo), ptr(roots), ptr(alphas), self.options.blowup_factor, ptr(rem))
+
+        def finish():
             host = ctx.to_host(back)                             # the one wait of the commit phase
+            coin.set_host_image(host[o_coin:])
+            h_roots = host[:o_alpha].reshape(nl + 1, 32)
+            channel.absorb_fri_layers(coin, h_roots[:nl], host[o_alpha:o_rem].view(np.uint64).reshape(nl, D * f.W), remainder_commitment=h_roots[nl])
+            for k in range(nl):
+                self.layers.append(FriLayer(MerkleTree(self.hasher, lv[k], nd[k], ctx), tr[k]))
+            self.remainder_poly = np.array(host[o_rem:o_coin].view(np.uint64).reshape(rem_size, D * f.W), copy=True)
+
+        try:
+            queue()
+            if defer:
+                # prove() against a device coin (prover/prove.py): the caller keeps queueing — grinding, the query draw — on the coin
+                # that now lives in `back`, and calls finish() when its own wait comes
+                return finish
+            finish()
         except Exception:
             # the device coin may have absorbed some of the layers: the channel's coin must not be used with a transcript that
             # no longer matches it
             if hasattr(channel, "invalidate_coin"):
                 channel.invalidate_coin()
             raise
-        coin.set_host_image(host[o_coin:])
-        h_roots = host[:o_alpha].reshape(nl + 1, 32)
-        channel.absorb_fri_layers(coin, h_roots[:nl], host[o_alpha:o_rem].view(np.uint64).reshape(nl, D * f.W), remainder_commitment=h_roots[nl])
-        for k in range(nl):
-            self.layers.append(FriLayer(MerkleTree(self.hasher, lv[k], nd[k], ctx), tr[k]))
-        self.remainder_poly = np.array(host[o_rem:o_coin].view(np.uint64).reshape(rem_size, D * f.W), copy=True)
 
     def _set_remainder(self, channel, ev, length):
         """mod.rs:230-239: interpolate over the coset, keep len/blowup coefficients in reverse order, commit to them."""

@@ -124,3 +124,32 @@ class DeepCompositionPoly:
         """composer/mod.rs:174-181: evaluations over the LDE domain (device vector)."""
         return fft.evaluate_poly_with_offset(self.coefficients, None, domain.offset, domain.blowup, ext_degree=self.ext_degree,
                                              ctx=self.ctx, field=self.field)
+
+
+# ---- the same steps with the point and the coefficients in DEVICE memory (prove() against a device coin, prover/prove.py) ------------
+def ood_frame_dev(m: ColMatrix, d_z, ext_degree):
+    """get_ood_frame with z where the device coin drew it: (2, num_cols, ext_degree*W) words on the device — row 0 at z, row 1 at
+    z*g, g = the generator of the column length's domain (poly_table.rs:68-76, composition_poly.rs:101-108).  No wait."""
+    f = m.field
+    out = m.ctx.empty_u64(2, m.num_cols(), ext_degree * f.W)
+    m.ctx.call("wf_polys_evaluate_at_dev", f.ID, m.ext_degree, ext_degree, ptr(m.data), m.num_cols(), m.col_stride(),
+               m.num_rows().bit_length() - 1, ptr(d_z), 1, ptr(out))
+    return out
+
+
+def deep_compose_dev(trace_polys: TracePolyTable, quotient_polys, d_z, d_cc, ext_degree):
+    """DeepCompositionPoly::add_trace_polys (composer/mod.rs:67-169) with z and the coefficients (trace columns first, then the
+    composition columns: DeepCompositionCoefficients in draw order) on the device -> a DeepCompositionPoly whose coefficients are set."""
+    main, q = trace_polys.main_trace_polys, quotient_polys.data
+    assert trace_polys.aux_trace_polys is None
+    f, ctx, D = main.field, main.ctx, ext_degree
+    n = trace_polys.poly_size()
+    assert q.num_rows() == n and q.ext_degree == D
+    assert d_cc.numel() == (main.num_cols() + q.num_cols()) * D * f.W
+    out = ctx.empty_u64(n * D * f.W)
+    ctx.call("wf_deep_compose_dev", f.ID, D, ptr(main.data), main.num_cols(), main.col_stride(), None, 0, 0, ptr(q.data), q.num_cols(),
+             q.col_stride(), n.bit_length() - 1, ptr(d_z), ptr(d_cc), ptr(out))
+    deep = DeepCompositionPoly.__new__(DeepCompositionPoly)
+    deep.z = deep.cc_trace = deep.cc_constraints = None          # filled in by the caller once it has read the transcript back
+    deep.ext_degree, deep.coefficients, deep.field, deep.ctx = D, out, f, ctx
+    return deep

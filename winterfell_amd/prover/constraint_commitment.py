@@ -55,11 +55,12 @@ class DefaultConstraintCommitment:
 
 
 def build_constraint_commitment(hasher, composition_trace, num_cols, domain, partition_options=None, ext_degree=1,
-                                field=fields.f64, ctx=None):
+                                field=fields.f64, ctx=None, fetch_root=True):
     """build_constraint_commitment (commitment/default.rs:109-150) -> (DefaultConstraintCommitment, CompositionPoly)."""
     poly = CompositionPoly.new(composition_trace, domain, num_cols, ext_degree, field, ctx)
     assert poly.num_columns() == num_cols and poly.column_degree() == domain.trace_length - 1
     # evaluate_composition_poly_columns + compute_constraint_evaluation_commitment: the columns already are polynomials
-    lde, tree, _ = build_trace_commitment(hasher, poly.data, domain, partition_options or PartitionOptions(), skip_interpolate=True)
+    lde, tree, _ = build_trace_commitment(hasher, poly.data, domain, partition_options or PartitionOptions(), skip_interpolate=True,
+                                          fetch_root=fetch_root)
     assert lde.num_cols() == num_cols and lde.num_rows() == domain.lde_domain_size()
     return DefaultConstraintCommitment(lde, tree), poly

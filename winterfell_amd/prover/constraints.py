@@ -80,3 +80,36 @@ class DefaultConstraintEvaluator:
                  domain.blowup.bit_length() - 1, air.ce_blowup_factor().bit_length() - 1, vp(off), vp(cct), len(self.assertions),
                  vp(cols), vp(steps), vp(vals), vp(ccb), ptr(out))
         return out
+
+
+def evaluate_constraints_dev(air, trace_lde, domain, d_cc, ext_degree=1):
+    """DefaultConstraintEvaluator::evaluate for a single-segment AIR with the composition coefficients where a DEVICE coin drew them:
+    d_cc = (num_transition_constraints + num_assertions) elements in draw order (transition first; boundary coefficient k belongs to
+    sorted assertion k, air/src/air/mod.rs:529-560).  One library call (wf_evaluate_constraints_dev), nothing waits for the stream.
+    Returns (CompositionPolyTrace on the device, the sorted assertions)."""
+    assert not air.is_multi_segment(), "the auxiliary segment's random elements are the caller's (host) input"
+    f, D = air.FIELD, ext_degree
+    lde = trace_lde.main_segment_lde
+    assert lde.num_rows() == domain.lde_domain_size() == air.lde_domain_size(), \
+        "extended trace length is not consistent with evaluation domain"                                 # default.rs:57-61
+    n, ctx = air.trace_length(), lde.ctx
+    ew = D * f.W
+    nt, assertions = air.num_transition_constraints(), air.sorted_assertions()
+    assert d_cc.numel() == (nt + len(assertions)) * ew
+    d_cc = d_cc.reshape(-1)
+    out = ctx.empty_u64(air.ce_domain_size() * ew)
+    for a in assertions:
+        if a.stride:
+            a.get_num_steps(n)                                                  # validate_trace_length
+    multi = any(a.stride for a in assertions)
+    cols = np.array([a.column for a in assertions], dtype=np.uint32)
+    steps = np.array([a.first_step for a in assertions], dtype=np.uint64)
+    strides = np.array([a.stride for a in assertions], dtype=np.uint64)
+    nvals = np.array([len(a.values) for a in assertions], dtype=np.uint64)
+    vals = f.pack([v for a in assertions for v in a.values]) if multi else f.pack([a.value for a in assertions])
+    off = f.element_words(int(domain.offset))
+    vp = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    ctx.call("wf_evaluate_constraints_dev", air.AIR_ID, f.ID, D, ptr(lde.data), lde.row_width, n.bit_length() - 1, domain.blowup.bit_length() - 1,
+             air.ce_blowup_factor().bit_length() - 1, vp(off), ptr(d_cc), len(assertions), vp(cols), vp(steps), vp(strides) if multi else None,
+             vp(nvals) if multi else None, vp(vals), ptr(d_cc[nt * ew:]), ptr(out))
+    return out, assertions

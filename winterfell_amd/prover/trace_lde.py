@@ -24,9 +24,10 @@ class StarkDomain:
         return self.blowup
 
 
-def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partition_options=None, skip_interpolate=False):
+def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partition_options=None, skip_interpolate=False, fetch_root=True):
     """build_trace_commitment (trace_lde/default/mod.rs:245-282): returns (trace_lde: RowMatrix, tree: MerkleTree,
-    trace_polys: ColMatrix).  One fused library call: interpolate -> coset LDE -> row hashes -> Merkle tree."""
+    trace_polys: ColMatrix).  One fused library call: interpolate -> coset LDE -> row hashes -> Merkle tree.
+    fetch_root=False: the call does not wait for the root (a caller that reseeds a DEVICE coin with tree.nodes_device[1])."""
     ctx = trace.ctx
     po = partition_options or PartitionOptions()
     n, b, D, f = trace.num_rows(), domain.blowup, trace.ext_degree, trace.field
@@ -42,7 +43,7 @@ def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partit
     off = f.element_words(int(domain.offset))
     ctx.call("wf_build_trace_commitment", hasher.HASH_ID, f.ID, D, ptr(polys), trace.num_cols(), trace.col_stride(), log_n, log_b,
              off.ctypes.data_as(ctypes.c_void_p), po.num_partitions, po.hash_rate or 256, int(skip_interpolate),
-             ptr(lde), ptr(leaves), ptr(nodes), root.ctypes.data_as(ctypes.c_void_p))
+             ptr(lde), ptr(leaves), ptr(nodes), root.ctypes.data_as(ctypes.c_void_p) if fetch_root else None)
     trace_lde = RowMatrix(lde, rw, trace.num_base_cols(), D, ctx, f)
     tree = MerkleTree(hasher, leaves, nodes, ctx)
     assert trace_lde.num_rows() == domain.lde_domain_size()
@@ -52,19 +53,19 @@ def build_trace_commitment(hasher, trace: ColMatrix, domain: StarkDomain, partit
 class DefaultTraceLde:
     """TraceLde implementation (trait: prover/src/trace/trace_lde/mod.rs:26-76)."""
 
-    def __init__(self, hasher, main_trace: ColMatrix, domain: StarkDomain, partition_options=None):
+    def __init__(self, hasher, main_trace: ColMatrix, domain: StarkDomain, partition_options=None, fetch_root=True):
         self.hasher = hasher
         self.partition_options = partition_options or PartitionOptions()
         self._blowup = domain.blowup
         self.main_segment_lde, self.main_segment_oracles, self.main_segment_polys = build_trace_commitment(
-            hasher, main_trace, domain, self.partition_options)
+            hasher, main_trace, domain, self.partition_options, fetch_root=fetch_root)
         self.aux_segment_lde = None
         self.aux_segment_oracles = None
 
     @classmethod
-    def new(cls, hasher, main_trace, domain, partition_options=None):
+    def new(cls, hasher, main_trace, domain, partition_options=None, fetch_root=True):
         """DefaultTraceLde::new (default/mod.rs:63-86) -> (trace_lde, trace_polys)."""
-        t = cls(hasher, main_trace, domain, partition_options)
+        t = cls(hasher, main_trace, domain, partition_options, fetch_root=fetch_root)
         return t, t.main_segment_polys
 
     def get_main_trace_commitment(self):
