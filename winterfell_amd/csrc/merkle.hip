@@ -88,7 +88,7 @@ __global__ __launch_bounds__(1024) void merkle_finish_kernel(const void *in, voi
             // the ticket word carries the epoch of its use in the high 12 bits: a word that is not in the state this launch expects — never
             // zeroed, shared with another tree in flight, written by something else — is REPORTED (the context's status word, checked by the
             // next synchronising call) instead of silently leaving the top of the tree unwritten
-            const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             const uint32_t seen = old & 0xfffffu;
             uint32_t last = 0;
             if ((old >> 20) != epoch || seen >= wgs) {
@@ -102,6 +102,9 @@ __global__ __launch_bounds__(1024) void merkle_finish_kernel(const void *in, voi
         }
         __syncthreads();
         if (!s_last) return;
+        // the last workgroup reads subtree tops written on other XCDs: EVERY wave acquires at device scope before its first such read
+        // (one wave's buffer_inv happens to invalidate the CU's L1 today; the memory model does not promise it) — 16 waves, once per tree
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         cnt = wgs;
         src = reinterpret_cast<const uint8_t *>(nodes) + cnt * 32;
         lc = 31 - __builtin_clz(wgs);
