@@ -456,9 +456,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             // `rem` (a tile's 16 columns = one 128-byte run): 16 coalesced loads replace the 15-multiplication chain
 #pragma unroll
             for (int ip = 0; ip < CNT; ip++) {
-                const int i = brev(ip, LOG_CNT);
-                const uint32_t kp = k0 + step_k * (uint32_t)ip;
-                (void)kp;
+                const int i = brev(ip, LOG_CNT);                 // register holding output digit k0 + step_k * ip
                 *out_next(ip == 0, (int64_t)step_k * o_step) = F::mul(val(i), tw0[((uint64_t)(step_k * (uint32_t)ip)) << log_s]);
             }
             return;
@@ -473,13 +471,10 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         }
 #pragma unroll
         for (int ip = 0; ip < CNT; ip++) {
-            const int i = brev(ip, LOG_CNT);                 // register holding output digit ip
-            const uint32_t kp = k0 + step_k * (uint32_t)ip;
+            const int i = brev(ip, LOG_CNT);                 // register holding output digit k0 + step_k * ip
 #ifdef NTT_EXPERIMENT_NO_CHAIN    // timing experiments only
-            (void)kp;
             *out_next(ip == 0, (int64_t)step_k * o_step) = val(i) ^ cur ^ stp;
 #else
-            (void)kp;
             *out_next(ip == 0, (int64_t)step_k * o_step) = F::mul(val(i), cur);
             if (ip + 1 < CNT) cur = F::mul(cur, stp);
 #endif
@@ -518,12 +513,10 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                     set_out_base((uint32_t)ka);
 #pragma unroll
                     for (int ip = 0; ip < B; ip++) {
-                        const int i = brev(ip, LOG_B);
-                        const uint32_t kp = (uint32_t)ka + (uint32_t)A * (uint32_t)ip;
+                        const int i = brev(ip, LOG_B);           // output digit k_a + A * ip
                         uint32_t yl[4];
 #pragma unroll
                         for (int q = 0; q < 4; q++) yl[q] = DB::limb(v, i, q);
-                        (void)kp;
                         const T *w = tw0 + 4 * (((uint64_t)A * (uint32_t)ip) << log_s);
                         *out_next(ip == 0, (int64_t)A * o_step) = l24::fold(l24::mul4(yl, w[0], w[1], w[2], w[3]));
                     }

@@ -22,7 +22,9 @@ def prove(air, trace: ColMatrix, options: ProofOptions, hasher, pub_inputs_eleme
     transcript = "device": the public coin lives on the device from the first commitment to the query positions
     (prove_device_transcript below: same proof, byte for byte, no host round trip in between); single-segment AIRs and the hashers
     with a device coin — anything else falls back to the host coin."""
-    if transcript == "device" and not air.is_multi_segment() and hasher.DEVICE_COIN and options.grinding_factor <= MAX_DEVICE_GRIND:
+    if transcript == "device" and not air.is_multi_segment() and hasher.DEVICE_COIN and options.grinding_factor <= MAX_DEVICE_GRIND and \
+            FriOptions(options.blowup_factor, options.fri_folding_factor, options.fri_remainder_max_degree, field=air.FIELD).num_fri_layers(
+                air.lde_domain_size()) > 0:
         return prove_device_transcript(air, trace, options, hasher, pub_inputs_elements, timings)
     f, ctx, D = air.FIELD, trace.ctx, options.ext_degree
     assert (build_aux_trace is not None) == air.is_multi_segment(), "a multi-segment AIR comes with Prover::build_aux_trace, the others without"
