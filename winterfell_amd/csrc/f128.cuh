@@ -3,7 +3,7 @@
 // The reference reduces with a 128x64 schoolbook scheme (mod.rs:429-466); any exact modmul gives the same canonical
 // result, so this one is built for gfx950 (no 64-bit multiplier, one instruction per limb of a carry chain, cf.
 // gl64.cuh): everything is written on 32-bit limbs with explicit carry chains.
-//   add 13 limb instructions + select, sub 11, mul = 16 + 6 v_mad_u64_u32 and ~60 carry/shift instructions:
+//   add 13 limb instructions + select, sub 11, mul = 16 + 6 v_mad_u64_u32 and ~50 carry instructions:
 //   the 256-bit product is folded with 2^128 = C (mod p), C = 45 * 2^40 - 1, i.e.  hi * C = ((hi * 45) << 40) - hi
 //   (a 32-bit multiply by 45 per limb instead of a 128 x 46-bit product), twice.
 // tools/microbench_f128.hip: mul 542 -> 310, add 90 -> 40, sub 79 -> 47 cycles per wave-op against the previous
@@ -116,22 +116,24 @@ F128_HD u128 mul(u128 a, u128 b) {
     P[5] = __builtin_addc(P[5], r[2], c, &c);
     P[6] = __builtin_addc(P[6], r[3], c, &c);
     P[7] = __builtin_addc(r[4], 0u, c, &c);
-    // ---- first fold: hi * C = ((hi * 45) << 40) - hi with hi = P[4..7] < p;  u = hi * 45 (5 limbs, u4 < 45)
+    // ---- first fold: hi * C = ((hi * 45) << 40) - hi with hi = P[4..7] < p.  The shift by 40 is a limb (32) and 8 bits: the 8 bits
+    // ride on the multiplier, u = hi * (45 << 8) (5 limbs, u4 < 2^14), so that v = u << 32 needs no funnel shifts (round 4: 7
+    // instructions of 74 with the second fold's two)
+    constexpr u32 K = 45u << 8;
     u32 u[5];
     {
-        u64 t = (u64)P[4] * 45u;
+        u64 t = (u64)P[4] * K;
         u[0] = (u32)t;
-        t = (u64)P[5] * 45u + (t >> 32);
+        t = (u64)P[5] * K + (t >> 32);
         u[1] = (u32)t;
-        t = (u64)P[6] * 45u + (t >> 32);
+        t = (u64)P[6] * K + (t >> 32);
         u[2] = (u32)t;
-        t = (u64)P[7] * 45u + (t >> 32);
+        t = (u64)P[7] * K + (t >> 32);
         u[3] = (u32)t;
         u[4] = (u32)(t >> 32);
     }
-    // v = u << 40 (limb 0 is zero), w = v - hi >= 0: six limbs, w5 < 2^14
-    const u32 v1 = u[0] << 8, v2 = funnel(u[1], u[0], 24), v3 = funnel(u[2], u[1], 24), v4 = funnel(u[3], u[2], 24),
-              v5 = funnel(u[4], u[3], 24);
+    // v = u << 32 (limb 0 is zero), w = v - hi >= 0: six limbs, w5 < 2^14
+    const u32 v1 = u[0], v2 = u[1], v3 = u[2], v4 = u[3], v5 = u[4];
     const u32 w0 = __builtin_subc(0u, P[4], 0u, &bw);
     const u32 w1 = __builtin_subc(v1, P[5], bw, &bw);
     const u32 w2 = __builtin_subc(v2, P[6], bw, &bw);
@@ -145,12 +147,12 @@ F128_HD u128 mul(u128 a, u128 b) {
     u32 r3 = __builtin_addc(P[3], w3, c, &c);
     const u32 T0 = __builtin_addc(w4, 0u, c, &k);
     const u32 T1 = w5 + k;
-    // ---- second fold: T * C = ((T * 45) << 40) - T < 2^93
-    u64 t = (u64)T0 * 45u;
+    // ---- second fold: T * C = ((T * 45) << 40) - T < 2^93, the same way: T * (45 << 8) < 2^61 is two limbs
+    u64 t = (u64)T0 * K;
     const u32 x0 = (u32)t;
-    t = (u64)T1 * 45u + (t >> 32);
-    const u32 x1 = (u32)t;                                         // T * 45 < 2^53: two limbs
-    const u32 y1 = x0 << 8, y2 = funnel(x1, x0, 24);               // (T * 45) << 40: limbs 1 and 2, limb 3 is zero
+    t = (u64)T1 * K + (t >> 32);
+    const u32 x1 = (u32)t;
+    const u32 y1 = x0, y2 = x1;                                    // (T * 45) << 40: limbs 1 and 2, limb 3 is zero
     const u32 z0 = __builtin_subc(0u, T0, 0u, &bw);
     const u32 z1 = __builtin_subc(y1, T1, bw, &bw);
     const u32 z2 = __builtin_subc(y2, 0u, bw, &bw);
