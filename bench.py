@@ -539,12 +539,12 @@ def main():
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/%s/bench_pmc_summary.json)" % pmc_round,
             "valu": valu,
-            "limiter": "co-limited by VALU issue and HBM: a pass executes ~90-115 wave-instructions per element (limb DFTs, two "
-                       "multiply-accumulate exits, the Montgomery chain of the twiddle progression; `valu` prices them), and the same tiles "
-                       "as a pure read-modify-write take 50 us per pass (5.4 TB/s), so three passes cap the fraction at 0.225 with free "
-                       "arithmetic.  Round 4 took 13 % of the instructions out (366 -> 317 per element: addresses) and the transform moved by "
-                       "0-4 %: neither bound alone explains the time, their imperfect overlap does.  HBM traffic = 1.02x the data per pass, "
-                       "three passes (a two-pass radix-4096 plan does not fit LDS with 128-byte row segments: DESIGN.md section 5)",
+            "limiter": "VALU issue, not HBM: a pass executes ~90-115 wave-instructions per element (limb DFTs, two multiply-accumulate "
+                       "exits, the Montgomery chain of the twiddle progression; `valu` prices them).  Round 4's experiments (DESIGN.md "
+                       "section 5.R4): with the arithmetic removed the same loads, LDS exchange and stores take 24.5 us per pass (the 256 MiB "
+                       "working set is served by the Infinity Cache) against 59; the time is the same with 2, 3 or 4 workgroups per CU; it "
+                       "follows the instruction count linearly (12 us + 0.019 us per instruction of a lane's tile).  HBM traffic = 1.02x the "
+                       "data per pass, three passes (a two-pass radix-4096 plan does not fit LDS with 128-byte row segments)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,

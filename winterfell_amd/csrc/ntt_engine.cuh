@@ -72,6 +72,8 @@ struct PassParams {
     // rows + leaves mode of the last pass (NttJob::rh_leaves, f64 + Blake3_256, rows of one 8-column group)
     uint32_t rh_log_cp;
     void *rh_leaves;
+    // launch stagger (experiment, WF_NTT_STAGGER="ticks,mode"): the first workgroups of a launch start `generation` x ticks x 10 ns late
+    uint32_t stagger_ticks, stagger_mode;
 };
 
 #ifndef NTT_WAVES_PER_EU
@@ -158,6 +160,20 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     __shared__ uint4 wlds[2 * WROWS];
 
     int tid = threadIdx.x;
+#ifdef NTT_EXTRA_LDS      // occupancy experiment (tools/build_variant.sh): bytes of LDS a workgroup holds on top of what it needs
+    __shared__ uint4 extra_lds[NTT_EXTRA_LDS / 16];
+    if (p.log_n == 77u) extra_lds[tid] = make_uint4(1, 2, 3, 4);      // never true: keeps the allocation alive
+#endif
+    if (!PF && p.stagger_ticks && blockIdx.x < 1024u) {
+        // The resident workgroups of a CU all start together and take equally long, so their load, arithmetic and store phases coincide
+        // launch after launch of replacements: skew the first generation (mode 0: generation = blockIdx / 256, one workgroup per CU and
+        // round of the dispatcher; mode 1: blockIdx % 4) and the replacements inherit the skew
+        const uint32_t g = p.stagger_mode == 0 ? (blockIdx.x >> 8) : (blockIdx.x & 3u);
+        if (g) {
+            const uint64_t t0 = wall_clock64();
+            while (wall_clock64() - t0 < (uint64_t)g * p.stagger_ticks) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     const uint32_t L = p.log_n;
     const uint64_t n = 1ull << L;
     const uint64_t ncols = n >> LOG_R;                     // columns per vector
@@ -800,6 +816,16 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     }
     p.rh_log_cp = rh_log_cp;
     p.rh_leaves = job.rh_leaves;
+    {
+        static const std::pair<uint32_t, uint32_t> stagger = [] {
+            const char *e = getenv("WF_NTT_STAGGER");
+            uint32_t t = 0, m = 0;
+            if (e) sscanf(e, "%u,%u", &t, &m);
+            return std::make_pair(t, m);
+        }();
+        p.stagger_ticks = stagger.first;
+        p.stagger_mode = stagger.second;
+    }
 
     const uint64_t n = 1ull << L;
     T *tmp = nullptr;
