@@ -66,6 +66,9 @@ __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint
     reinterpret_cast<uint64_t *>(out)[gid] = reinterpret_cast<const uint64_t *>(rows + pos[r] * row_bytes)[w];
 }
 
+#ifndef WF_HASH_WAVES
+#define WF_HASH_WAVES 4      // waves per SIMD the wide-row hash kernels are compiled for (occupancy experiment: tools/build_variant.sh)
+#endif
 // Row hashes for rows of >= 64 bytes, BLAKE3 family.  One row per lane as in hash_rows_kernel, but a lane walking its own row
 // reads 8 bytes per load at a row-sized stride (measured 0.26 TB/s on 256-byte rows: 32 columns x 2^23 rows took 8.4 ms for
 // 1.3 ms of compressions).  Here a wavefront owns 64 consecutive rows and brings the message in one 64-byte block at a time:
@@ -73,7 +76,7 @@ __global__ void gather_rows_kernel(const uint8_t *rows, uint64_t row_bytes, uint
 // canonicalised once by the loading lane, staged through 4.5 KiB of LDS per wavefront (wave-synchronous: DS operations of
 // one wavefront execute in order), and every lane reads back its own row's 16 message words.
 template <class H, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_rows_wide_kernel(const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_HASH_WAVES, WF_HASH_WAVES))) void hash_rows_wide_kernel(const uint64_t *rows, uint64_t num_rows, uint64_t row_width, uint32_t elems_per_row,
                                                              uint32_t part_elems, uint32_t parts, void *out) {
     constexpr int BW = H::WIDE_BW;                                    // 64-bit words per message block (BLAKE3 8, SHA3 17)
     constexpr int PITCH = BW | 1;                                     // odd: lanes reading their own rows hit distinct banks
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // complete: the lane keeps one chaining value and at most one pending digest instead of all of them.  Round 2 wrote the
 // 32 parts N bytes of partition digests to HBM and read them back in a second launch (configs[3]: 8 GiB each way).
 template <int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void hash_rows_parts_blake3_kernel(const uint64_t *rows, uint64_t num_rows,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(WF_HASH_WAVES, WF_HASH_WAVES))) void hash_rows_parts_blake3_kernel(const uint64_t *rows, uint64_t num_rows,
                                                                                                               uint64_t row_width, uint32_t elems_per_row,
                                                                                                               uint32_t part_elems, uint32_t parts, void *out) {
     constexpr int BW = 8, PITCH = BW | 1;
