@@ -239,8 +239,9 @@ int wf_grind(wf_ctx *ctx, int hash, const void *h_seed, uint32_t grinding_factor
  *   wf_coin_reseed_draw  reseed with d_digest, then one draw, in one launch (commit_fri_layer + draw_fri_alpha)
  *   wf_coin_read    waits for the stream; h_seed / h_counter := the state; WF_ERR_NOT_FOUND if a draw used up its 1000
  *                   tries (the reference's RandomCoinError::FailedToDrawFieldElement) */
-/* state layout: bytes [0, 32) the seed digest, [32, 40) the counter (little-endian u64), [40, 44) non-zero once a draw has
- * failed, the rest reserved — a caller may also write / read the 64 bytes itself instead of wf_coin_init / wf_coin_read */
+/* state layout: bytes [0, 32) the seed digest, [32, 40) the counter (little-endian u64), [40, 44) a little-endian u32 of failure
+ * bits — bit 0: a draw ran out of its 1000 tries, bit 1: wf_coin_grind found no nonce in its range ("nonce not found") —, the rest
+ * reserved — a caller may also write / read the 64 bytes itself instead of wf_coin_init / wf_coin_read */
 #define WF_COIN_BYTES 64
 int wf_coin_init(wf_ctx *ctx, void *d_coin, const void *h_seed);
 int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d_digest, void *d_digest_copy);
@@ -253,8 +254,8 @@ int wf_coin_read(wf_ctx *ctx, const void *d_coin, void *h_seed, uint64_t *h_coun
  *   wf_coin_grind          ProverChannel::grind_query_seed (prover/src/channel.rs:169-185): *d_nonce := the smallest nonce in
  *                          [1, 2^log_max_tries] with check_leading_zeros(nonce) >= grinding_factor for the coin's CURRENT seed (the coin
  *                          is not changed); a fixed queue of batches in increasing order, each returning at once when an earlier one
- *                          has found a nonce, so nothing is read back in between.  No nonce in the range: the coin's failed flag
- *                          (wf_coin_read: WF_ERR_NOT_FOUND).  log_max_tries <= grinding_factor + 12 keeps the queue short; the search
+ *                          has found a nonce, so nothing is read back in between.  No nonce in the range: bit 1 of the coin's
+ *                          failure word (wf_coin_read: WF_ERR_NOT_FOUND; the coin is still reseeded by a later wf_coin_draw_integers).  log_max_tries <= grinding_factor + 12 keeps the queue short; the search
  *                          fails with probability exp(-2^(log_max_tries - grinding_factor)).
  *   wf_coin_draw_integers  RandomCoin::draw_integers (crypto/src/random/default.rs:209-248): seed := merge_with_int(seed, *d_nonce),
  *                          counter := 0, d_out[i] := the first 8 bytes of next(), little-endian, masked to 2^log_domain_size, for

@@ -169,6 +169,9 @@ class DeviceCoin:
     def read(self):
         """(seed, counter) after everything queued so far; raises like the reference when a draw ran out of tries"""
         img = self._host_image if self._host_image is not None else self.ctx.to_host(self._upload())
-        if int.from_bytes(img[40:44].tobytes(), "little"):
+        failed = int.from_bytes(img[40:44].tobytes(), "little")
+        if failed & 2:          # wf_coin_grind searched its whole range (the reference panics: channel.rs:169-185)
+            raise RuntimeError("nonce not found")
+        if failed:
             raise RuntimeError("FailedToDrawFieldElement(1000)")
         return np.array(img[:32], copy=True), int.from_bytes(img[32:40].tobytes(), "little")

@@ -138,9 +138,10 @@ __global__ __launch_bounds__(256) void coin_grind_kernel(const CoinState *c, uin
     if (tz >= factor) atomicMin(best, (unsigned long long)(first + gid));
 }
 
-// no nonce in the searched range: the coin's failed flag (wf_coin_read -> WF_ERR_NOT_FOUND)
+// no nonce in the searched range: bit 1 of the coin's failed flag (bit 0 = a draw ran out of tries), so that the host can tell the
+// reference's "nonce not found" panic (prover/src/channel.rs:169-185) from FailedToDrawFieldElement; wf_coin_read -> WF_ERR_NOT_FOUND
 __global__ void coin_grind_check_kernel(CoinState *c, const unsigned long long *best) {
-    if (*best == ~0ull) c->failed = 1;
+    if (*best == ~0ull) c->failed |= 2u;
 }
 
 // RandomCoin::draw_integers (crypto/src/random/default.rs:209-248): seed = merge_with_int(seed, nonce), counter = 0, then

@@ -228,13 +228,25 @@ extern "C" int wf_debug_guard_mode(void) { return guard_mode(); }
 namespace {
 constexpr size_t BOUNCE_BYTES = 4u << 20;
 
-bool host_range_is_pinned(const void *p) {
+bool host_byte_is_pinned(const void *p) {
     hipPointerAttribute_t a{};
     if (hipPointerGetAttributes(&a, p) != hipSuccess) {
         (void)hipGetLastError();
         return false;
     }
     return a.type == hipMemoryTypeHost;
+}
+// the WHOLE range [p, p + bytes) must be page-locked: the first and the last byte, and every 2 MiB in between (registrations are
+// page-granular; two separate registrations that happen to be adjacent are both valid for the copy engine).  A range that is
+// pinned only at its head goes through the bounce buffers like pageable memory.
+bool host_range_is_pinned(const void *p, size_t bytes) {
+    if (!host_byte_is_pinned(p)) return false;
+    if (bytes <= 1) return true;
+    const char *c = (const char *)p;
+    if (!host_byte_is_pinned(c + bytes - 1)) return false;
+    for (size_t off = (size_t)2 << 20; off < bytes - 1; off += (size_t)2 << 20)
+        if (!host_byte_is_pinned(c + off)) return false;
+    return true;
 }
 
 int ensure_bounce(wf_ctx *ctx) {
@@ -249,7 +261,7 @@ int ensure_bounce(wf_ctx *ctx) {
 
 int wf_copy_h2d(wf_ctx *ctx, void *d_dst, const void *h_src, size_t bytes) {
     if (bytes == 0) return WF_OK;
-    if (host_range_is_pinned(h_src)) {
+    if (host_range_is_pinned(h_src, bytes)) {
         WF_HIP(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, ctx->stream));
         WF_HIP(hipStreamSynchronize(ctx->stream));
         return WF_OK;
@@ -275,8 +287,17 @@ int wf_copy_h2d_small_async(wf_ctx *ctx, void *d_dst, const void *h_src, size_t 
     const uint32_t i = ctx->stage_next;
     ctx->stage_next = (i + 1) % wf_ctx::STAGE_SLOTS;
     if (!ctx->h_stage[i]) {
-        WF_HIP(hipHostMalloc(&ctx->h_stage[i], wf_ctx::STAGE_BYTES, hipHostMallocDefault));
-        WF_HIP(hipEventCreateWithFlags(&ctx->stage_ev[i], hipEventDisableTiming));
+        // the slot is published only when both the buffer and its event exist
+        void *buf = nullptr;
+        hipEvent_t ev = nullptr;
+        WF_HIP(hipHostMalloc(&buf, wf_ctx::STAGE_BYTES, hipHostMallocDefault));
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) {
+            (void)hipGetLastError();
+            (void)hipHostFree(buf);
+            return WF_ERR_HIP;
+        }
+        ctx->h_stage[i] = buf;
+        ctx->stage_ev[i] = ev;
     }
     if (ctx->stage_busy[i]) WF_HIP(hipEventSynchronize(ctx->stage_ev[i]));   // the copy that last read this slot (eight uploads ago)
     memcpy(ctx->h_stage[i], h_src, bytes);
@@ -291,7 +312,7 @@ int wf_copy_d2h(wf_ctx *ctx, void *h_dst, const void *d_src, size_t bytes) {
         WF_HIP(hipStreamSynchronize(ctx->stream));
         return WF_OK;
     }
-    if (host_range_is_pinned(h_dst)) {
+    if (host_range_is_pinned(h_dst, bytes)) {
         WF_HIP(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
         WF_HIP(hipStreamSynchronize(ctx->stream));
         return WF_OK;
@@ -475,6 +496,14 @@ static void pool_release_cached(wf_ctx *ctx) {
 extern "C" int wf_malloc(wf_ctx *ctx, size_t bytes, void **d_ptr) {
     WF_ENTER(ctx);
     if (!d_ptr) return WF_ERR_INVALID_ARG;
+    if (guard_mode()) {
+        // electric-fence sessions: no size classes and no caching — the block is exactly `bytes` long, so its last byte sits on the
+        // last mapped byte (pool_round would leave up to 2 MiB - 1 mapped bytes behind it), and it is unmapped when it is released
+        WF_HIP(hipSetDevice(ctx->device));
+        WF_TRY(wf_dev_malloc(ctx, d_ptr, bytes ? bytes : 1));
+        ctx->pool_live[*d_ptr] = bytes ? bytes : 1;
+        return WF_OK;
+    }
     const size_t want = pool_round(bytes);
     // best fit among the cached blocks, wasting at most a quarter of the block
     auto it = ctx->pool_free.lower_bound(want);
@@ -504,6 +533,10 @@ extern "C" int wf_free(wf_ctx *ctx, void *d_ptr) {
     if (it == ctx->pool_live.end()) return WF_ERR_INVALID_ARG;
     const size_t sz = it->second;
     ctx->pool_live.erase(it);
+    if (guard_mode()) {
+        WF_HIP(hipStreamSynchronize(ctx->stream));       // queued kernels may still use the block
+        return wf_dev_free(ctx, d_ptr);
+    }
     ctx->pool_free.emplace(sz, d_ptr);
     ctx->pool_free_bytes += sz;
     // keep at most 64 GiB cached (of 288): beyond that return the largest blocks to the driver
@@ -671,7 +704,9 @@ int wf_resident_blocks(wf_ctx *ctx, const void *kernel, uint32_t *out) {
 
 // ---- scratch ---------------------------------------------------------------------------------------
 int wf_scratch(wf_ctx *ctx, int slot, size_t bytes, void **out) {
-    if (ctx->scratch_bytes[slot] < bytes) {
+    // electric-fence sessions: the slot is re-allocated at the exact size of every request (grow-only slots would leave a request
+    // below the high-water mark with mapped memory behind it); the contents of a slot never outlive the library call that asked
+    if (ctx->scratch_bytes[slot] < bytes || (guard_mode() && ctx->scratch_bytes[slot] != bytes)) {
         if (ctx->scratch[slot]) {
             WF_HIP(hipStreamSynchronize(ctx->stream));
             WF_TRY(wf_dev_free(ctx, ctx->scratch[slot]));

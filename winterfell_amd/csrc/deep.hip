@@ -703,7 +703,7 @@ extern "C" int wf_polys_evaluate_at_dev(wf_ctx *ctx, int field, uint32_t poly_ex
     WF_ENTER(ctx);
     if (!ctx || !d_polys || !d_point || !d_out) return WF_ERR_INVALID_ARG;
     if (num_cols == 0) return WF_OK;
-    if (col_stride < ((uint64_t)poly_ext_degree << log_n)) return WF_ERR_INVALID_ARG;
+    if (col_stride < ((uint64_t)poly_ext_degree << log_n) || num_cols > 65535) return WF_ERR_INVALID_ARG;   // grid.y = num_cols
     switch (field) {
         case WF_FIELD_F64: return evaluate_at_dev_dispatch<HostF64>(ctx, poly_ext_degree, ext_degree, d_polys, num_cols, col_stride, log_n, d_point, with_next != 0, d_out);
         case WF_FIELD_F128: return evaluate_at_dev_dispatch<HostF128>(ctx, poly_ext_degree, ext_degree, d_polys, num_cols, col_stride, log_n, d_point, with_next != 0, d_out);
@@ -718,7 +718,12 @@ extern "C" int wf_deep_compose_dev(wf_ctx *ctx, int field, uint32_t ext_degree, 
                                    const void *d_z, const void *d_cc, void *d_out) {
     WF_ENTER(ctx);
     if (!ctx || !d_z || !d_cc || !d_out || log_n == 0) return WF_ERR_INVALID_ARG;
-    if ((num_main && !d_main_polys) || (num_aux && !d_aux_polys) || (num_quotient && !d_quotient_polys)) return WF_ERR_INVALID_ARG;
+    // the same argument checks as the host-coin twin (a short stride would make deep_acc_kernel read out of bounds)
+    if ((num_main && (!d_main_polys || main_stride < (1ull << log_n))) ||
+        (num_aux && (!d_aux_polys || aux_stride < ((uint64_t)ext_degree << log_n))) ||
+        (num_quotient && (!d_quotient_polys || quotient_stride < ((uint64_t)ext_degree << log_n))))
+        return WF_ERR_INVALID_ARG;
+    if (num_main + num_aux + num_quotient == 0) return WF_ERR_INVALID_ARG;
     switch (field) {
         case WF_FIELD_F64: return compose_dev_dispatch<HostF64>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, d_z, d_cc, d_out);
         case WF_FIELD_F128: return compose_dev_dispatch<HostF128>(ctx, ext_degree, d_main_polys, num_main, main_stride, d_aux_polys, num_aux, aux_stride, d_quotient_polys, num_quotient, quotient_stride, log_n, d_z, d_cc, d_out);

@@ -72,8 +72,10 @@ struct PassParams {
     // rows + leaves mode of the last pass (NttJob::rh_leaves, f64 + Blake3_256, rows of one 8-column group)
     uint32_t rh_log_cp;
     void *rh_leaves;
+#ifdef WF_EXPERIMENTS
     // launch stagger (experiment, WF_NTT_STAGGER="ticks,mode"): the first workgroups of a launch start `generation` x ticks x 10 ns late
     uint32_t stagger_ticks, stagger_mode;
+#endif
 };
 
 #ifndef NTT_WAVES_PER_EU
@@ -160,10 +162,11 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     __shared__ uint4 wlds[2 * WROWS];
 
     int tid = threadIdx.x;
-#ifdef NTT_EXTRA_LDS      // occupancy experiment (tools/build_variant.sh): bytes of LDS a workgroup holds on top of what it needs
+#if defined(WF_EXPERIMENTS) && defined(NTT_EXTRA_LDS)      // occupancy experiment (tools/build_variant.sh): bytes of LDS a workgroup holds on top of what it needs
     __shared__ uint4 extra_lds[NTT_EXTRA_LDS / 16];
     if (p.log_n == 77u) extra_lds[tid] = make_uint4(1, 2, 3, 4);      // never true: keeps the allocation alive
 #endif
+#ifdef WF_EXPERIMENTS
     if (!PF && p.stagger_ticks && blockIdx.x < 1024u) {
         // The resident workgroups of a CU all start together and take equally long, so their load, arithmetic and store phases coincide
         // launch after launch of replacements: skew the first generation (mode 0: generation = blockIdx / 256, one workgroup per CU and
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             while (wall_clock64() - t0 < (uint64_t)g * p.stagger_ticks) __builtin_amdgcn_s_sleep(16);
         }
     }
+#endif
     const uint32_t L = p.log_n;
     const uint64_t n = 1ull << L;
     const uint64_t ncols = n >> LOG_R;                     // columns per vector
@@ -612,9 +616,16 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     }   // tiles
 }
 
-// the prefetching (persistent) variants exist for the radices whose tiles are big enough to be latency bound, f64 only
+// the prefetching (persistent) variants exist for the radices whose tiles are big enough to be latency bound, f64 only; they lost in
+// round 2 (see PF above) and are compiled only into experiment builds (-DWF_EXPERIMENTS, tools/build_variant.sh)
 template <class F, int LA, int LB>
-constexpr bool has_prefetch_variant() { return F::USE_L24 && LA + LB >= 6; }
+constexpr bool has_prefetch_variant() {
+#ifdef WF_EXPERIMENTS
+    return F::USE_L24 && LA + LB >= 6;
+#else
+    return false;
+#endif
+}
 
 template <class F, int LA, int LB>
 constexpr bool has_rows_variant() { return F::USE_L24 && LA == LB && LB >= 3; }
@@ -647,7 +658,13 @@ auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false) -> 
 }
 
 template <class F>
-static bool prefetch_variant_exists(uint32_t r) { return F::USE_L24 && r >= 6; }
+static bool prefetch_variant_exists(uint32_t r) {
+#ifdef WF_EXPERIMENTS
+    return F::USE_L24 && r >= 6;
+#else
+    return false;
+#endif
+}
 
 inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
 
@@ -816,6 +833,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     }
     p.rh_log_cp = rh_log_cp;
     p.rh_leaves = job.rh_leaves;
+#ifdef WF_EXPERIMENTS
     {
         static const std::pair<uint32_t, uint32_t> stagger = [] {
             const char *e = getenv("WF_NTT_STAGGER");
@@ -826,6 +844,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         p.stagger_ticks = stagger.first;
         p.stagger_mode = stagger.second;
     }
+#endif
 
     const uint64_t n = 1ull << L;
     T *tmp = nullptr;
