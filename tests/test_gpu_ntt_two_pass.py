@@ -1,0 +1,170 @@
+"""GPU parity of the two-pass NTT plans (csrc/ntt_big.cuh: three-step passes of radix 2^10 .. 2^12) against the CPU oracle, bit
+for bit: math::fft evaluate / interpolate (math/src/fft/mod.rs:85-386) at 2^20 .. 2^24 points, extension fields, coset
+evaluation / interpolation, and the batched row-major LDE behind RowMatrix::evaluate_polys_over
+(prover/src/matrix/row_matrix.rs:84-100) with ragged column groups.  The host-side emulation of the same code
+(tests/cpp/ntt_big_host_test.cpp, run by test_host_logic.py) covers the index arithmetic without a GPU."""
+import numpy as np
+import pytest
+
+from conftest import P, rand_field
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(request):
+    """a context of its own with WF_NTT_BIG=1 (read once, by wf_ctx_create): every eligible f64 transform takes two passes"""
+    import os
+    import winterfell_amd
+    from winterfell_amd._lib import Context
+    from winterfell_amd.math import fft, fields
+    old = os.environ.get("WF_NTT_BIG")
+    os.environ["WF_NTT_BIG"] = "1"
+    try:
+        ctx = Context(winterfell_amd.default_context().device.index or 0)
+    finally:
+        if old is None:
+            del os.environ["WF_NTT_BIG"]
+        else:
+            os.environ["WF_NTT_BIG"] = old
+    yield ctx, fft, fields
+    ctx.sync()
+    ctx.close()
+
+
+def _launches(ctx, fn):
+    ctx.prof_enable(True)
+    fn()
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    return prof
+
+
+@pytest.mark.parametrize("log_n", [20, 21, 22, 23, 24])
+def test_two_pass_transform_vs_oracle(big, oracle, log_n):
+    ctx, fft, fields = big
+    n = 1 << log_n
+    p = oracle.f64_from_int(rand_field(1000 + log_n, n))
+    want = oracle.evaluate_poly(p, par=True)
+    got = fft.evaluate_poly(p.copy(), ctx=ctx)
+    assert np.array_equal(got, want), "evaluate_poly n=2^%d" % log_n
+    assert np.array_equal(fft.interpolate_poly(got.copy(), ctx=ctx), p), "round trip n=2^%d" % log_n
+    assert np.array_equal(fft.interpolate_poly(p.copy(), ctx=ctx), oracle.interpolate_poly(p, par=True))
+    # the plan is in force: two launches of the three-step kernels
+    prof = _launches(ctx, lambda: fft.evaluate_poly(p.copy(), ctx=ctx))
+    assert sorted(prof) == ["ntt_pass3", "ntt_pass3_last"] and all(c == 1 for c, _ in prof.values()), prof
+
+
+def test_edge_values_two_pass(big, oracle):
+    ctx, fft, fields = big
+    n = 1 << 20
+    for fill in (0, 1, P - 1):
+        p = oracle.f64_from_int(np.full(n, fill, dtype=np.uint64))
+        assert np.array_equal(fft.evaluate_poly(p.copy(), ctx=ctx), oracle.evaluate_poly(p, par=True)), fill
+    p = np.zeros(n, dtype=np.uint64)
+    p[n - 1] = oracle.f64_from_int(np.array([P - 1], dtype=np.uint64))[0]
+    assert np.array_equal(fft.evaluate_poly(p.copy(), ctx=ctx), oracle.evaluate_poly(p, par=True))
+
+
+@pytest.mark.parametrize("D", [2, 3])
+def test_extension_fields_two_pass(big, oracle, D):
+    ctx, fft, fields = big
+    n = 1 << 20
+    p = oracle.f64_from_int(rand_field(D * 7 + 1, n * D))
+    assert np.array_equal(fft.evaluate_poly(p.copy(), ext_degree=D, ctx=ctx), oracle.evaluate_poly(p, D=D, par=True))
+    assert np.array_equal(fft.interpolate_poly(p.copy(), ext_degree=D, ctx=ctx), oracle.interpolate_poly(p, D=D, par=True))
+    off = fields.new(7)
+    assert np.array_equal(fft.evaluate_poly_with_offset(p, None, off, 2, ext_degree=D, ctx=ctx),
+                          oracle.evaluate_poly_with_offset(p, off, 2, D=D, par=True))
+    assert np.array_equal(fft.interpolate_poly_with_offset(p.copy(), None, off, ext_degree=D, ctx=ctx),
+                          oracle.interpolate_poly_with_offset(p, off, D=D))
+
+
+@pytest.mark.parametrize("log_n,blowup", [(20, 8), (21, 2), (22, 4)])
+def test_with_offset_two_pass(big, oracle, log_n, blowup):
+    ctx, fft, fields = big
+    n = 1 << log_n
+    p = oracle.f64_from_int(rand_field(log_n * 31 + blowup, n))
+    for off_int in (7, P - 1):
+        off = fields.new(off_int)
+        got = fft.evaluate_poly_with_offset(p, None, off, blowup, ctx=ctx)
+        assert np.array_equal(got, oracle.evaluate_poly_with_offset(p, off, blowup, par=True)), (log_n, blowup, off_int)
+    ev = oracle.f64_from_int(rand_field(99 + log_n, n))
+    assert np.array_equal(fft.interpolate_poly_with_offset(ev.copy(), None, fields.new(7), ctx=ctx),
+                          oracle.interpolate_poly_with_offset(ev, fields.new(7)))
+
+
+def test_batched_vectors_two_pass(big, oracle):
+    ctx, fft, fields = big
+    n, batch = 1 << 20, 5
+    p = oracle.f64_from_int(rand_field(5, n * batch)).reshape(batch, n)
+    got = np.asarray(fft.evaluate_poly(p.copy(), batch=batch, ctx=ctx)).reshape(batch, n)
+    for v in range(batch):
+        assert np.array_equal(got[v], oracle.evaluate_poly(p[v], par=True)), v
+
+
+@pytest.fixture(scope="module")
+def big_rm():
+    """WF_NTT_BIG=1 and WF_ROWS_HASH_WIDE=0: every eligible transform in two passes, wide rows stored row-major by the last three-step
+    pass (the leaves come from the separate row-hash kernel)"""
+    import os
+    import winterfell_amd
+    from winterfell_amd._lib import Context
+    os.environ["WF_NTT_BIG"] = "1"
+    os.environ["WF_ROWS_HASH_WIDE"] = "0"
+    try:
+        ctx = Context(winterfell_amd.default_context().device.index or 0)
+    finally:
+        del os.environ["WF_NTT_BIG"]
+        del os.environ["WF_ROWS_HASH_WIDE"]
+    yield ctx
+    ctx.sync()
+    ctx.close()
+
+
+SHAPES = [
+    (8, 20, 2),       # one group of eight columns, radix-1024 passes (tiles of eight columns)
+    (12, 20, 2),      # a group of eight + a ragged one, padding to sixteen
+    (5, 21, 2),       # groups of four (radix 2^11 / 2^10), one ragged, padding to eight
+    (32, 20, 8),      # the bench shape at 2^20 rows
+    (9, 22, 1),       # 2^22-point columns, two radix-2048 passes, blowup 1
+    (20, 19, 4),      # padded row of 24 columns in a 32-column tile (radix-64 last pass), three-pass plan
+    (16, 18, 8),      # rows of exactly sixteen columns
+]
+
+
+def _commit_and_compare(oracle, ctx, c, log_n, blowup):
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    n = 1 << log_n
+    trace = oracle.f64_from_int(rand_field(c * 1000 + log_n, n * c)).reshape(c, n)
+    ctx.prof_enable(True)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(ctx.to_device(trace), 1, ctx), prover.StarkDomain(n, blowup))
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(0, trace, blowup, fields.new(7), par=True)
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    assert np.array_equal(lde.to_host(), o_lde), "lde"
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"
+    return prof
+
+
+@pytest.mark.parametrize("c,log_n,blowup", SHAPES)
+def test_trace_commitment_default_plans_vs_oracle(oracle, c, log_n, blowup):
+    """wf_build_trace_commitment on the DEFAULT context, every word against the oracle: rows of 9 .. 32 f64 columns get their
+    Blake3_256 leaves from the last NTT pass (rows + leaves mode for wide rows: no row-hash launch), batches of 2^20-point vectors
+    take the two-pass plan by themselves"""
+    import winterfell_amd
+    prof = _commit_and_compare(oracle, winterfell_amd.default_context(), c, log_n, blowup)
+    if 8 < c <= 32 and not (log_n + (blowup.bit_length() - 1) >= 24 and c > 16):
+        assert "ntt_pass_last_rows_hash" in prof and "hash_rows_blake3" not in prof, prof
+    if log_n == 20:
+        assert "ntt_pass3_last" in prof, prof          # the interpolation of >= 8 columns
+
+
+@pytest.mark.parametrize("c,log_n,blowup", SHAPES[:5])
+def test_trace_commitment_two_pass_row_major_vs_oracle(oracle, big_rm, c, log_n, blowup):
+    """the same with the row-major store of the three-step last pass (ragged column groups, zero padding)"""
+    prof = _commit_and_compare(oracle, big_rm, c, log_n, blowup)
+    assert "ntt_pass3_last" in prof and (c <= 8 or "ntt_pass_last_rows_hash" not in prof), prof

@@ -208,3 +208,24 @@ def test_limb_arithmetic_of_the_f64_ntt_passes_on_the_host(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("ok")
+
+
+def test_three_step_ntt_passes_emulated_on_the_host(tmp_path):
+    """winterfell_amd/csrc/ntt_big.cuh (the two-pass f64 NTT plans: three-step passes of radix 2^10 / 2^11) compiled as plain C++
+    — tests/cpp/stub/hip/hip_runtime.h stands in for the HIP runtime header — and run lane by lane, workgroup by workgroup: forward
+    and inverse transforms, the coset-scaled inverse, and the batched row-major LDE with ragged column groups against a textbook
+    radix-2 transform on canonical integers.  The same step functions are what the GPU kernel calls between its barriers
+    (tests/test_gpu_ntt_two_pass.py is the device-side parity test)."""
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"          # __builtin_addc / __builtin_subc of the field headers are clang builtins
+    if not os.path.exists(clang):
+        clang = shutil.which("clang++")
+    if not clang:
+        pytest.skip("no clang++")
+    exe = str(tmp_path / "ntt_big_host_test")
+    subprocess.check_call([clang, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tests", "cpp", "stub"),
+                           os.path.join(ROOT, "tests", "cpp", "ntt_big_host_test.cpp"), "-o", exe])
+    out = subprocess.run([exe, "21"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.strip().endswith("all ok")

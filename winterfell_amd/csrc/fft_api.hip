@@ -211,7 +211,12 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
     uint32_t log_i = 0;
     const uint32_t max_log_i = sizeof(T) > 8 && WF_RM_MAX_LOG_I > 4 ? 4 : WF_RM_MAX_LOG_I;   // 256-byte segments
     while (log_i < max_log_i && (2u << log_i) <= base_cols) log_i++;
-    if (((size_t)sizeof(T) << log_i) >= 64) {
+    // Blake3_256 leaves wanted and a padded row fits the columns of a last-pass tile (f64, <= 32 columns; <= 16 when the last pass has
+    // radix 256): the last pass itself stores the rows, stages them in LDS and hashes them (ntt_pass<..., RH>) — for rows wider than
+    // one 8-column group this replaces the row-major store below AND the row-hash kernel's second read of the whole matrix
+    const bool rows_hash = hash == WF_HASH_BLAKE3_256 && d_leaves && (row_width == 8 || ctx->rows_hash_wide) &&
+                           wf_ntt_rows_mode_ok(HF::Dev::ID, log_n, log_blowup, base_cols);
+    if (!rows_hash && ((size_t)sizeof(T) << log_i) >= 64) {
         // wide rows: the last pass stores straight into the row-major matrix, >= 64 contiguous bytes per row and column
         // group, and zeroes the padding columns (NttJob::rowmajor).  Measured on 64 x 2^22 f128 columns: the separate
         // transpose (12.8 ms of 154) disappears and the last pass costs the same.
@@ -224,7 +229,7 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
         return wf_ntt_run(ctx, j);
     }
 #ifndef WF_NO_ROWS_HASH_PASS
-    if (hash == WF_HASH_BLAKE3_256 && d_leaves && row_width == 8 && wf_ntt_rows_mode_ok(HF::Dev::ID, log_n, log_blowup, base_cols)) {
+    if (rows_hash) {
         // narrow rows, Blake3_256 leaves wanted: the last pass itself assembles the rows in LDS, hashes them and stores rows +
         // leaves (ntt_pass<..., RH>): no coset-major buffer, no transpose launch
         j.dst = d_lde;

@@ -34,71 +34,18 @@
 #include "blake3.cuh"
 #include "dft_regs.cuh"
 #include "l24.cuh"
+#include "ntt_params.cuh"
+#include "ntt_big.cuh"
 #include "tables.cuh"
 #include "wf_internal.h"
 
 namespace {
-
-template <class T>
-struct PassParams {
-    const T *src;
-    T *dst;
-    uint32_t log_n;
-    uint32_t npass;
-    uint32_t pass;
-    uint32_t log_r[6];
-    uint32_t nvec;
-    uint32_t src_div, src_inner, dst_inner;
-    uint64_t src_vec_stride, dst_vec_stride;
-    uint64_t src_inner_stride, dst_inner_stride;
-    uint32_t src_es, dst_es;
-    uint32_t inverse;
-    // tables
-    const T *w_lo, *w_hi;
-    uint32_t w_log_lo;
-    const T *w256, *w16;
-    const T *pre_lo, *pre_hi;
-    uint32_t pre_log_lo, pre_mod;
-    uint64_t pre_lo_stride, pre_hi_stride;
-    const T *post_lo, *post_hi;
-    uint32_t post_log_lo;
-    uint32_t has_post_const;
-    T post_const;
-    const T *tw_tab;          // non-last pass: inter-pass twiddles T[k'][rem] when the table is small (else nullptr: progression)
-    uint32_t scale_in_w256;   // last pass of an inverse transform: w256 already carries the 1/n (applied for k_a = 0 too)
-    // row-major output mode of the last pass (NttJob::rowmajor)
-    uint32_t rowmajor, rm_log_b, rm_log_i, rm_base_cols;
-    uint64_t rm_row_width;
-    // rows + leaves mode of the last pass (NttJob::rh_leaves, f64 + Blake3_256, rows of one 8-column group)
-    uint32_t rh_log_cp;
-    void *rh_leaves;
-#ifdef WF_EXPERIMENTS
-    // launch stagger (experiment, WF_NTT_STAGGER="ticks,mode"): the first workgroups of a launch start `generation` x ticks x 10 ns late
-    uint32_t stagger_ticks, stagger_mode;
-#endif
-};
 
 #ifndef NTT_WAVES_PER_EU
 #define NTT_WAVES_ATTR
 #else
 #define NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(NTT_WAVES_PER_EU, NTT_WAVES_PER_EU)))
 #endif
-
-// q = x / d, r = x % d for a wave-uniform divisor that is almost always 1 or a power of two (blowup, extension degree):
-// a runtime 64-bit division costs ~30-100 VALU instructions per lane, this costs a shift
-__device__ __forceinline__ void divmod_uniform(uint32_t x, uint32_t d, uint32_t &q, uint32_t &r) {
-    if (d == 1) {
-        q = x;
-        r = 0;
-    } else if ((d & (d - 1)) == 0) {
-        const uint32_t sh = 31u - (uint32_t)__builtin_clz(d);
-        q = x >> sh;
-        r = x & (d - 1);
-    } else {
-        q = x / d;
-        r = x - q * d;
-    }
-}
 
 // TWTAB (non-last passes): the inter-pass twiddles come from the pass's L2-resident table (p.tw_tab) instead of the per-lane
 // progression; a compile-time switch so that neither variant carries the other's registers
@@ -124,7 +71,7 @@ __device__ __forceinline__ void divmod_uniform(uint32_t x, uint32_t d, uint32_t 
 template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : 1))) void ntt_pass(PassParams<typename F::T> p) {
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
-    static_assert(!RH || (LAST && !PF && F::USE_L24 && LOG_A == LOG_B && LOG_B >= 3), "rows mode: f64 last passes of radix 64 / 256");
+    static_assert(!RH || (LAST && !PF && F::USE_L24 && LOG_B >= 3), "rows mode: f64 last passes of radix 64 / 128 / 256");
     static_assert(!(PF && TWTAB), "the table kernel's step-2 loads would drain the prefetch (in-order vm counter)");
     typedef typename F::T T;
     constexpr int A = 1 << LOG_A, B = 1 << LOG_B, LOG_R = LOG_A + LOG_B;
@@ -413,7 +360,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
             o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
             if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 ? 4 : 1) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
-        } else if (RM) {
+        } else if (RM || (RH && p.rh_log_cp > 3)) {
             // LDE row u + b * m, column bc
             o_ptr = o_ptr0 = p.dst + (u2 + ((c + ncols * (uint64_t)kbase) << p.rm_log_b)) * p.rm_row_width + bc2;
             o_step = (int64_t)((ncols << p.rm_log_b) * p.rm_row_width);
@@ -441,7 +388,21 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     };
     auto emit = [&](T val, uint32_t kp, uint32_t krel, int64_t stride) {
         if constexpr (RH) {
-            lds[kp * TC + t2] = val;        // staged: [output digit k'][tile column], rows are taken from here below
+            // staged: [output digit k'][tile column], rows are taken from here below
+            const uint32_t log_cp = p.rh_log_cp;
+            if (log_cp <= 3) {
+                lds[kp * TC + t2] = val;    // rows of one 8-column group: stored by the lanes that hash them
+                return;
+            }
+            // wide rows (16 / 32 padded columns, 128 / 256 bytes): the lanes of step 2 store the row segment themselves (consecutive
+            // lanes = consecutive columns), the staged copy is only read by the hashing lanes: word c of row r sits at (c + r) mod cp2
+            // of the row, so that lanes walking their own rows hit different banks
+            const uint32_t cp2m = (1u << log_cp) - 1;
+            const uint32_t rowid = (kp << ((8 - LOG_B) - log_cp)) + ((uint32_t)t2 >> log_cp);
+            lds[kp * TC + ((uint32_t)t2 & ~cp2m) + ((((uint32_t)t2 & cp2m) + rowid) & cp2m)] = val;
+            T *cell = out_next(krel == 0, stride);
+            if (real_col) *cell = val;
+            else if (bc2 < p.rm_row_width) *cell = F::zero();
             return;
         }
         if (RM) {
@@ -510,16 +471,26 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             for (int ip = 0; ip < A; ip++) emit(x[brev(ip, LOG_A)], (uint32_t)ip, (uint32_t)ip, o_step);
         }
     } else {
+        // RH: the exchange buffer becomes the row staging area, so every lane takes ALL its inputs (both B-point DFTs of a radix-128
+        // pass) before the first output is staged
+        T yall[RH ? G : 1][B];
+        if constexpr (RH) {
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int bb = 0; bb < B; bb++) yall[g][bb] = lds[idx_l(q2 + B * g, t2, bb)];
+            __syncthreads();
+        }
 #pragma unroll
         for (int g = 0; g < G; g++) {
             const int ka = q2 + B * g;
             T y[B];
 #pragma unroll
             for (int bb = 0; bb < B; bb++) {
-                if (!LAST) y[bb] = lds[idx_nl(ka, bb * TC + t2)];
+                if constexpr (RH) y[bb] = yall[g][bb];
+                else if (!LAST) y[bb] = lds[idx_nl(ka, bb * TC + t2)];
                 else y[bb] = lds[idx_l(ka, t2, bb)];
             }
-            if constexpr (RH) __syncthreads();   // every lane holds its inputs: the exchange buffer becomes the row staging area
             if constexpr (F::USE_L24) {
                 typedef l24::Dft<LOG_B> DB;
                 int32_t v[DB::NV];
@@ -579,6 +550,29 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         const uint32_t log_rpk = LOG_TC - log_cp;                        // rows per output digit
         const uint32_t nrows = (1u << LOG_R) << log_rpk;
         const uint64_t j0 = cc0 >> log_cp, kp_stride = ncols << p.rm_log_b;
+        if (log_cp > 3) {
+            // wide rows: one BLAKE3 chunk of up to four blocks per row, message words straight from the staged tile
+            const uint32_t cp2m = cp2 - 1, base_cols = p.rm_base_cols;
+            for (uint32_t r = (uint32_t)tid; r < nrows; r += 256) {
+                const uint32_t kp = r >> log_rpk, jl = r & ((1u << log_rpk) - 1);
+                const uint64_t row = j0 + jl + kp_stride * kp;
+                const T *rw = lds + kp * TC + (jl << log_cp);
+                auto fetch = [&](uint32_t blk, uint32_t, uint32_t (&m)[16]) {
+#pragma unroll
+                    for (uint32_t i = 0; i < 8; i++) {
+                        const uint32_t col = 8 * blk + i;
+                        const uint64_t vi = col < base_cols ? gl::to_int((uint64_t)rw[(col + r) & cp2m]) : 0ull;
+                        m[2 * i] = (uint32_t)vi;
+                        m[2 * i + 1] = (uint32_t)(vi >> 32);
+                    }
+                };
+                uint32_t d[8];
+                b3::chunk_blocks(fetch, 0, base_cols * 2, 0, true, d);
+                uint4 *q = reinterpret_cast<uint4 *>(p.rh_leaves) + row * 2;
+                q[0] = make_uint4(d[0], d[1], d[2], d[3]);
+                q[1] = make_uint4(d[4], d[5], d[6], d[7]);
+            }
+        } else
         for (uint32_t r = (uint32_t)tid; r < nrows; r += 256) {
             const uint32_t kp = r >> log_rpk, jl = r & ((1u << log_rpk) - 1);
             const uint64_t row = j0 + jl + kp_stride * kp;
@@ -628,7 +622,7 @@ constexpr bool has_prefetch_variant() {
 }
 
 template <class F, int LA, int LB>
-constexpr bool has_rows_variant() { return F::USE_L24 && LA == LB && LB >= 3; }
+constexpr bool has_rows_variant() { return F::USE_L24 && (LA == LB || LA == LB + 1) && LB >= 3; }
 
 template <class F, int LA, int LB>
 auto pick(bool last, bool twtab, bool pf, bool rh = false) -> void (*)(PassParams<typename F::T>) {
@@ -652,7 +646,7 @@ auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false) -> 
         case 4: return pick<F, 2, 2>(last, twtab, pf);
         case 5: return pick<F, 3, 2>(last, twtab, pf);
         case 6: return pick<F, 3, 3>(last, twtab, pf, rh);
-        case 7: return pick<F, 4, 3>(last, twtab, pf);
+        case 7: return pick<F, 4, 3>(last, twtab, pf, rh);
         default: return pick<F, 4, 4>(last, twtab, pf, rh);
     }
 }
@@ -673,9 +667,22 @@ inline uint32_t log_b_for(uint32_t r) { return r == 1 ? 0 : r / 2; }
 // Split L bits into passes of at most max_bits bits, as evenly as possible (largest first).  max_bits is 8 for the
 // 64-bit fields; f128 uses 6: a radix-256 pass of 16-byte elements needs 207 VGPRs and 70 KB of LDS per workgroup
 // (2 waves per SIMD), a radix-64 pass 116 VGPRs and 35 KB (4 waves per SIMD), which more than pays for the extra pass.
-static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, uint32_t log_r[6]) {
+#ifndef NTT_RH32_PLAN
+#define NTT_RH32_PLAN 1
+#endif
+static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, uint32_t log_r[6], bool rows32 = false) {
     npass = (L + max_bits - 1) / max_bits;
     if (npass == 0) npass = 1;
+    if (NTT_RH32_PLAN && rows32 && L == 22 && max_bits == 8) {
+        // rows + leaves for rows of 17 .. 32 columns: the radix-64 last pass (68 VGPRs, 18 KiB of LDS: many workgroups per CU to
+        // run beside the lanes that hash) instead of the radix-128 one of the 7, 8, 7 plan
+        npass = 3;
+        log_r[0] = 8;
+        log_r[1] = 8;
+        log_r[2] = 6;
+        for (uint32_t q = 3; q < 6; q++) log_r[q] = 0;
+        return;
+    }
     if (npass == 3 && max_bits == 8 && L >= 18) {
         // three radix <= 256 passes: the widest in the middle, the rest split evenly with the first pass the larger one — measured over
         // every split of 2^18 .. 2^23 points (tools/time_batch_ntt.py with WF_NTT_PLAN): 2^20: 6,8,6 417 us against 7,7,6 436 and
@@ -697,16 +704,17 @@ static inline void plan_passes(uint32_t L, uint32_t max_bits, uint32_t &npass, u
     for (uint32_t q = npass; q < 6; q++) log_r[q] = 0;
 }
 
-// the rows + leaves mode exists for f64 when the last pass of the plan has radix 64 or 256 and tiles are whole
+// the rows + leaves mode exists for f64 when the last pass of the plan has radix 64 .. 256, a (padded) row fits the tile's columns
+// (32 for radix 64 / 128, 16 for radix 256) and tiles are whole
 template <class F>
 static bool rows_mode_ok(uint32_t L, uint32_t log_b, uint32_t base_cols) {
-    if (!F::USE_L24 || base_cols == 0 || base_cols > 8) return false;
-    uint32_t npass, log_r[6];
-    plan_passes(L, F::MAX_LOG_RADIX, npass, log_r);
-    const uint32_t r = log_r[npass - 1];
-    if (r != 6 && r != 8) return false;
+    if (!F::USE_L24 || base_cols == 0 || base_cols > 32) return false;
     uint32_t log_cp = 0;
     while ((1u << log_cp) < base_cols) log_cp++;
+    uint32_t npass, log_r[6];
+    plan_passes(L, F::MAX_LOG_RADIX, npass, log_r, log_cp == 5);
+    const uint32_t r = log_r[npass - 1];
+    if (r < 6 || r > 8) return false;
     const uint32_t log_tc = 8 - r / 2;
     return (L - r) + log_b + log_cp >= log_tc && log_cp <= log_tc;
 }
@@ -776,6 +784,36 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
     return WF_OK;
 }
 
+// one three-step pass (ntt_big.cuh): radix 2^10 (tile 1024 x 8), 2^11 (2048 x 4) or 2^12 (4096 x 4, one 1024-lane workgroup per CU)
+template <int LB, int LC, int LTC, bool HALF>
+static int launch_big_pass_t(wf_ctx *ctx, const PassParams<uint64_t> &p, bool last, uint64_t total_cols) {
+    typedef nttbig::Geo<LB, LC, LTC> G;
+    constexpr size_t smem = nttbig::smem_bytes<LB, LC, LTC, HALF>();
+    const uint64_t blocks = (total_cols + G::TC - 1) / G::TC;
+    if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+    typedef void (*fn)(PassParams<uint64_t>);
+    const fn k = last ? (fn)nttbig::ntt_pass3<LB, LC, LTC, true, HALF> : (fn)nttbig::ntt_pass3<LB, LC, LTC, false, HALF>;
+    static bool attr_set[2] = {false, false};       // per instantiation (function-local statics of a template)
+    if (!attr_set[last ? 1 : 0]) {
+        WF_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        attr_set[last ? 1 : 0] = true;
+    }
+    wf_prof_begin(ctx, last ? "ntt_pass3_last" : "ntt_pass3");
+    hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(G::NT), smem, ctx->stream, p);
+    wf_prof_end(ctx);
+    WF_HIP(hipGetLastError());
+    return WF_OK;
+}
+template <class HF>      // a template so that only the f64 translation unit instantiates the kernels
+static int launch_big_pass(wf_ctx *ctx, const PassParams<uint64_t> &p, uint32_t r, bool last, uint64_t total_cols) {
+    switch (r) {
+        case 10: return launch_big_pass_t<3, 3, 3, false>(ctx, p, last, total_cols);
+        case 11: return launch_big_pass_t<3, 4, 2, true>(ctx, p, last, total_cols);
+        case 12: return launch_big_pass_t<4, 4, 2, true>(ctx, p, last, total_cols);
+        default: return WF_ERR_UNSUPPORTED;
+    }
+}
+
 template <class HF>
 static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     typedef typename HF::Dev F;
@@ -792,6 +830,26 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         if (fits) {
             p.npass = ctx->plan_npass;
             for (uint32_t q = 0; q < 6; q++) p.log_r[q] = ctx->plan_log_r[q];
+        }
+    }
+    // Two passes of radix 2^10 .. 2^12 (ntt_big.cuh) instead of three of radix <= 256: a third less traffic, the same number of
+    // register steps and general multiplications, one LDS exchange more.  Measured (tools/time_two_pass.py):
+    // it wins for single 2^21 / 2^22-point transforms (-14 % / -9 %) and for batches of 2^20-point vectors (radix 1024, tiles of
+    // eight columns = 64-byte segments: -8 %); the radix-2048 tiles of four columns (32-byte segments) lose on batches that stream
+    // from HBM (+14 % at 2^22 x 288), the radix-4096 pass (one 1024-lane workgroup per CU) loses everywhere (2^24: 229 against
+    // 193 us).  WF_NTT_BIG=1 forces the plan for every eligible transform, 0 switches it off.
+    bool big = false;
+    if constexpr (F::USE_L24) {
+        const bool plan_forced = ctx->plan_log_n == L && ctx->plan_npass;
+        const uint32_t r_last = L / 2, log_tc_last = r_last == 10 ? 3 : 2;
+        const bool wins = (L == 20 && job.nvec >= 8) || ((L == 21 || L == 22) && job.nvec < 8);
+        const bool wanted = ctx->ntt_big == 1 || (ctx->ntt_big < 0 && wins);
+        big = wanted && !plan_forced && L >= 20 && L <= 24 && job.rh_leaves == nullptr && (!job.rowmajor || job.rm_log_i >= log_tc_last);
+        if (big) {
+            p.npass = 2;
+            p.log_r[0] = (L + 1) / 2;
+            p.log_r[1] = L / 2;
+            for (uint32_t q = 2; q < 6; q++) p.log_r[q] = 0;
         }
     }
     p.nvec = job.nvec;
@@ -827,12 +885,14 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     const bool rh = job.rh_leaves != nullptr;
     uint32_t rh_log_cp = 0;
     if (rh) {
-        if (job.rowmajor || job.rm_row_width != 8 || job.nvec != (job.rm_base_cols << job.rm_log_b) || !rows_mode_ok<F>(L, job.rm_log_b, job.rm_base_cols))
+        if (job.rowmajor || job.rm_row_width != 8 * ((job.rm_base_cols + 7) / 8) || job.nvec != (job.rm_base_cols << job.rm_log_b) ||
+            !rows_mode_ok<F>(L, job.rm_log_b, job.rm_base_cols))
             return WF_ERR_INVALID_ARG;
         while ((1u << rh_log_cp) < job.rm_base_cols) rh_log_cp++;
     }
     p.rh_log_cp = rh_log_cp;
     p.rh_leaves = job.rh_leaves;
+    if (rh && rh_log_cp == 5) plan_passes(L, F::MAX_LOG_RADIX, p.npass, p.log_r, true);
 #ifdef WF_EXPERIMENTS
     {
         static const std::pair<uint32_t, uint32_t> stagger = [] {
@@ -895,6 +955,22 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             else WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
             p.w256 = (const T *)ws;
             p.scale_in_w256 = 1;
+        }
+        if constexpr (F::USE_L24) {
+            if (big) {
+                void *bt;
+                WF_TRY(wf_get_big_table<HF>(ctx, r, &bt));
+                p.big_tab = (const T *)bt;
+                p.tw_tab = nullptr;
+                p.rowmajor = (last && job.rowmajor) ? 1 : 0;
+                uint64_t cols = (n >> r) * (uint64_t)job.nvec;
+                if (p.rowmajor) {
+                    const uint64_t groups = (job.rm_base_cols + (1u << job.rm_log_i) - 1) >> job.rm_log_i;
+                    cols = (groups << (job.rm_log_b + job.rm_log_i)) * (n >> r);
+                }
+                WF_TRY(launch_big_pass<HF>(ctx, p, r, last, cols));
+                continue;
+            }
         }
         const uint32_t Tc = 256u >> log_b_for(r);
         uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;

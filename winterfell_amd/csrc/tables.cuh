@@ -137,6 +137,28 @@ static int wf_get_w256_4form(wf_ctx *ctx, typename HF::T c, void **out) {
     return WF_OK;
 }
 
+// three-step passes (ntt_big.cuh): omega_R^e, e < R = 2^log_r, internal form, 8 bytes each
+template <class HF>
+static int wf_get_big_table(wf_ctx *ctx, uint32_t log_r, void **out) {
+    typedef typename HF::T T;
+    static_assert(sizeof(T) == 8, "three-step passes exist for the 64-bit Goldilocks field only");
+    auto it = ctx->big_tables.find(log_r);
+    if (it == ctx->big_tables.end()) {
+        std::vector<T> h((size_t)1 << log_r);
+        const T w = HF::root_of_unity(log_r);
+        T cur = HF::from_u64(1);
+        for (size_t i = 0; i < h.size(); i++) {
+            h[i] = HF::to_internal(cur);
+            cur = HF::mulmod(cur, w);
+        }
+        void *p;
+        WF_TRY(wf_upload(ctx, h, &p));
+        it = ctx->big_tables.emplace(log_r, p).first;
+    }
+    *out = it->second;
+    return WF_OK;
+}
+
 // LDE pre-scale tables: for coset u (rows u + b*m of the LDE), series (offset * g^u)^j, j < n, g = omega_{n*b}
 template <class HF>
 static int wf_get_lde_tables(wf_ctx *ctx, typename HF::T offset_canon, uint32_t log_n, uint32_t log_b, wf_ctx::LdeTables *out,

@@ -95,6 +95,14 @@ struct wf_ctx {
     // WF_NTT_PREFETCH=1 switches the persistent, next-tile-prefetching NTT launches on.  Off by default: measured slower on
     // MI355X (2^24 f64: 304 us vs 227 us; the 32 extra VGPRs cost a wave per SIMD)
     bool ntt_prefetch = false;
+    // Two-pass plans with three-step passes of radix 2^10 .. 2^12 (ntt_big.cuh) for f64 transforms of 2^20 .. 2^24 points.
+    // WF_NTT_BIG (read once at context creation): 0 = never, 1 = every eligible transform, unset = the default of ntt_run
+    // (batched transforms, where the data stream from HBM and a pass less is worth more than the instructions it costs)
+    int ntt_big = -1;
+    std::map<uint32_t, void *> big_tables;     // log_r -> omega_R^e, e < R (f64 Montgomery residues)
+    // WF_ROWS_HASH_WIDE=0 (read once at context creation): rows wider than one 8-column group are hashed by the separate row-hash
+    // kernel instead of the last NTT pass (A/B measurements)
+    bool rows_hash_wide = true;
     // WF_NTT_PLAN, parsed once at context creation (context.hip): a pass plan for transforms of 2^plan_log_n points, 0 = none
     uint32_t plan_log_n = 0, plan_npass = 0, plan_log_r[6] = {0, 0, 0, 0, 0, 0};
 
