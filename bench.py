@@ -222,6 +222,29 @@ def comm_abi_legs(ctx, dist, rank, world, barrier, timeout_s=240.0, log_rows=22,
     return res
 
 
+def stall_breakdown(c):
+    """Where a wave's cycles go, from the committed counter passes of the 2^24 transform (sums over its three launches): the three
+    disjoint buckets of SQ_WAVE_CYCLES — parked (SQ_WAIT_ANY: s_waitcnt / barrier), stalled at issue (SQ_WAIT_INST_ANY, of which
+    SQ_WAIT_INST_LDS is the LDS part) and issuing (the rest) —, and the instruction mix per wave."""
+    wc = c.get("SQ_WAVE_CYCLES")
+    if not wc:
+        return None
+    frac = lambda k: (c[k] / wc) if k in c else None
+    out = {"of_wave_cycles": {"parked_waitcnt_or_barrier (SQ_WAIT_ANY)": frac("SQ_WAIT_ANY"),
+                              "issue_stall (SQ_WAIT_INST_ANY)": frac("SQ_WAIT_INST_ANY"),
+                              "issue_stall_lds (SQ_WAIT_INST_LDS, part of the above)": frac("SQ_WAIT_INST_LDS"),
+                              "vmem_inst_cycles (SQ_INST_CYCLES_VMEM)": frac("SQ_INST_CYCLES_VMEM"),
+                              "active_inst_any (SQ_ACTIVE_INST_ANY)": frac("SQ_ACTIVE_INST_ANY")},
+           "raw_per_transform": {k: v for k, v in sorted(c.items())}}
+    if c.get("SQ_WAVES"):
+        w = c["SQ_WAVES"]
+        out["per_wave"] = {k: c[k] / w for k in ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR", "SQ_INSTS_SMEM",
+                                                  "SQ_WAVE_CYCLES", "SQ_LDS_BANK_CONFLICT") if k in c}
+    if c.get("SQ_BUSY_CYCLES") and c.get("GRBM_GUI_ACTIVE"):
+        out["sq_busy_over_gui_active"] = c["SQ_BUSY_CYCLES"] / c["GRBM_GUI_ACTIVE"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -303,6 +326,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # the first five steps on a box as it comes (tables built by an untimed step first): reported beside the steady number as
+    # ms_per_step_cold, so that what the untimed spin-up below is worth can be read from the line itself
+    step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    barrier()
+    cold_ms = (time.perf_counter() - t0) * 1e3 / 5
+    if dist is not None:
+        t = torch.tensor([cold_ms], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        cold_ms = float(t.item())
     # steady clocks first (not part of --warmup, not timed): see spin_up
     spinup_s, spinup_ok, _ = spin_up(step, torch.cuda.synchronize, min_s=args.spinup_s) if args.spinup_s > 0 else (0.0, False, None)
     for _ in range(args.warmup):
@@ -331,6 +367,7 @@ def main():
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": ms_per_step,
+        "ms_per_step_cold": cold_ms, "cold_steps": 5,
         "spinup_s": round(spinup_s, 3), "spinup_converged": bool(spinup_ok),
         "higher_is_better": True,
         **({"INVALID": "timing experiment: results not checked"} if experiment else {}),
@@ -505,7 +542,7 @@ def main():
         # the gfx950 correction + WRITE_SIZE, summed over the transform's launches); only valid for the profiled size
         traffic, valu, pmc_round = None, None, None
         try:
-            pmc_round = next(r for r in ("r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
+            pmc_round = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
             with open(os.path.join(ROOT, "profiles", pmc_round, "bench_pmc_summary.json")) as f:
                 pmf = json.load(f)
             if args.log_n == 24:
@@ -513,11 +550,15 @@ def main():
                 # the second bound: wave-instructions per element (SQ_INSTS_VALU; on this chip SQ_ACTIVE_INST_VALU reports the same
                 # number, i.e. it counts instructions, not cycles), priced at the two issue rates below
                 insts = 0.0
+                stall = {}
                 for kname, cs in pmf["kernels"].items():
                     if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or kname.rstrip().split("(")[0].endswith(", true>"):
                         continue                       # (the rows + leaves variant of the last pass belongs to the LDE, not to a transform)
                     per_transform = 1 if "ntt_pass<F64, 4, 4, true," in kname else 2       # the last pass once, the other shape twice
                     insts += per_transform * cs["SQ_INSTS_VALU"]["avg"] * 64 / n
+                    for cname, cv in cs.items():           # every SQ / GRBM counter of the committed passes, summed over the transform's launches
+                        if cname.startswith(("SQ_", "GRBM_")):
+                            stall[cname] = stall.get(cname, 0.0) + per_transform * cv["avg"]
                 if insts:
                     ghz = (sclk_mhz or 2400.0) * 1e-3
                     wave_insts = insts * n / 64.0
@@ -527,6 +568,7 @@ def main():
                             "issue_us_if_every_inst_were_fast": wave_insts * VALU_FAST_CYCLES / (1024 * ghz * 1e9) * 1e6,
                             "issue_us_if_every_inst_were_slow": wave_insts * VALU_SLOW_CYCLES / (1024 * ghz * 1e9) * 1e6,
                             "measured_us": fwd_us,
+                            "stall_breakdown": stall_breakdown(stall),
                             "what": "SQ_INSTS_VALU (wave-instructions, summed over the transform's launches) priced at the two issue rates "
                                     "tools/microbench_isa.hip measures on this chip: %.1f cycles per wave-instruction on a SIMD for plain 32-bit "
                                     "add / sub / and / xor / shift / mov, %.1f for everything else (multiply-adds, carry producers and consumers, "
@@ -657,7 +699,7 @@ def main():
             # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 per the gfx950 correction; tools/summarize_workloads_pmc.py)
             wl_traffic, wl_round = {}, None
             try:
-                wl_round = next(r for r in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
+                wl_round = next(r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
                 with open(os.path.join(ROOT, "profiles", wl_round, "workloads_pmc_summary.json")) as f:
                     wl_traffic = json.load(f)["workloads"]
             except Exception:
@@ -718,6 +760,32 @@ def main():
             lde_commit_case("2^22x32_b8_f64_blake3", fields.f64, crypto.Blake3_256, 22, 32, reps=2)
             lde_commit_case("2^24x4_b8_f64_blake3", fields.f64, crypto.Blake3_256, 24, 4, reps=2)
             lde_commit_case("2^22x64_b8_f128_blake3_p8", fields.f128, crypto.Blake3_256, 22, 64, parts=8, reps=2)
+            # the rest of the reference's row_matrix bench widths (prover/benches/row_matrix.rs: 2^19 rows x 64 / 96 columns)
+            lde_commit_case("2^19x64_b8_f64_blake3", fields.f64, crypto.Blake3_256, 19, 64, reps=2)
+            lde_commit_case("2^19x96_b8_f64_blake3", fields.f64, crypto.Blake3_256, 19, 96, reps=2)
+
+            # standalone 2^20-point transforms over the other fields of math/benches/fft.rs:16-116 (f128, f62, and the quadratic /
+            # cubic extensions of f64): forward transform, kernel events, algorithmic bytes 2 n e (read once, write once)
+            def ntt_case(key, field, D, log_rows=20):
+                try:
+                    rows = 1 << log_rows
+                    if field is fields.f64:
+                        d_ = ctx.to_device(rng.integers(0, fields.M, rows * D, dtype=np.uint64))
+                    elif field is fields.f128:
+                        d_ = ctx.to_device(rng.integers(0, 1 << 62, rows * D * 2, dtype=np.uint64))
+                    else:
+                        d_ = ctx.to_device(rng.integers(0, 1 << 61, rows * D, dtype=np.uint64))
+                    run_ = lambda: fft.evaluate_poly(d_, ext_degree=D, field=field)
+                    ms_, ks_ = kernel_ms(run_, 10)
+                    rl["ntt_" + key] = roof(2.0 * rows * D * 8 * field.W, ms_, ks_, "2 n e: read once, write once (one forward transform, in place)",
+                                            "ntt_" + key)
+                except Exception as e:
+                    ex["ntt_" + key + "_error"] = repr(e)[:160]
+
+            ntt_case("2^20_f128", fields.f128, 1)
+            ntt_case("2^20_f62", fields.f62, 1)
+            ntt_case("2^20_f64_quad", fields.f64, 2)
+            ntt_case("2^20_f64_cubic", fields.f64, 3)
             # Rescue: hopeless against HBM, so its rate is permutations per second against the measured modular-multiplication
             # ceiling.  2^20 x 4, blowup 8: one permutation per row (4 elements < rate 8) + one per Merkle merge.
             perms = 2.0 * (1 << 23) - 1

@@ -40,7 +40,7 @@ def _launches(ctx, fn):
     return prof
 
 
-@pytest.mark.parametrize("log_n", [20, 21, 22, 23, 24])
+@pytest.mark.parametrize("log_n", [20, 21, 22])
 def test_two_pass_transform_vs_oracle(big, oracle, log_n):
     ctx, fft, fields = big
     n = 1 << log_n
@@ -53,6 +53,28 @@ def test_two_pass_transform_vs_oracle(big, oracle, log_n):
     # the plan is in force: two launches of the three-step kernels
     prof = _launches(ctx, lambda: fft.evaluate_poly(p.copy(), ctx=ctx))
     assert sorted(prof) == ["ntt_pass3", "ntt_pass3_last"] and all(c == 1 for c, _ in prof.values()), prof
+
+
+@pytest.mark.parametrize("log_n", [23, 24])
+def test_two_pass_equals_three_pass_at_full_size(big, log_n):
+    """radix-4096 passes (one 1024-lane workgroup per CU): the two plans against each other, word for word, and the round trip; the
+    three-pass plan is the one tests/test_gpu_fft.py holds against the oracle at these sizes"""
+    import torch
+    import winterfell_amd
+    ctx, fft, fields = big
+    base = winterfell_amd.default_context()
+    n = 1 << log_n
+    d = base.to_device(np.random.default_rng(log_n).integers(0, fields.M, n, dtype=np.uint64))
+    want = fft.evaluate_poly(d.clone(), ctx=base)
+    got = fft.evaluate_poly(d.clone(), ctx=ctx)
+    base.sync()
+    ctx.sync()
+    assert torch.equal(got, want)
+    back = fft.interpolate_poly(got, ctx=ctx)
+    ctx.sync()
+    assert torch.equal(back, d)
+    prof = _launches(ctx, lambda: fft.evaluate_poly(d.clone(), ctx=ctx))
+    assert sorted(prof) == ["ntt_pass3", "ntt_pass3_last"], prof
 
 
 def test_edge_values_two_pass(big, oracle):
@@ -80,7 +102,7 @@ def test_extension_fields_two_pass(big, oracle, D):
                           oracle.interpolate_poly_with_offset(p, off, D=D))
 
 
-@pytest.mark.parametrize("log_n,blowup", [(20, 8), (21, 2), (22, 4)])
+@pytest.mark.parametrize("log_n,blowup", [(20, 4), (21, 2)])
 def test_with_offset_two_pass(big, oracle, log_n, blowup):
     ctx, fft, fields = big
     n = 1 << log_n
@@ -126,8 +148,8 @@ SHAPES = [
     (8, 20, 2),       # one group of eight columns, radix-1024 passes (tiles of eight columns)
     (12, 20, 2),      # a group of eight + a ragged one, padding to sixteen
     (5, 21, 2),       # groups of four (radix 2^11 / 2^10), one ragged, padding to eight
-    (32, 20, 8),      # the bench shape at 2^20 rows
-    (9, 22, 1),       # 2^22-point columns, two radix-2048 passes, blowup 1
+    (9, 21, 1),       # 2^21-point columns, radix-2048 + radix-1024 passes, blowup 1
+    (32, 18, 8),      # rows of 32 columns
     (20, 19, 4),      # padded row of 24 columns in a 32-column tile (radix-64 last pass), three-pass plan
     (16, 18, 8),      # rows of exactly sixteen columns
 ]
@@ -163,8 +185,58 @@ def test_trace_commitment_default_plans_vs_oracle(oracle, c, log_n, blowup):
         assert "ntt_pass3_last" in prof, prof          # the interpolation of >= 8 columns
 
 
-@pytest.mark.parametrize("c,log_n,blowup", SHAPES[:5])
+@pytest.mark.parametrize("c,log_n,blowup", SHAPES[:4])
 def test_trace_commitment_two_pass_row_major_vs_oracle(oracle, big_rm, c, log_n, blowup):
     """the same with the row-major store of the three-step last pass (ragged column groups, zero padding)"""
     prof = _commit_and_compare(oracle, big_rm, c, log_n, blowup)
     assert "ntt_pass3_last" in prof and (c <= 8 or "ntt_pass_last_rows_hash" not in prof), prof
+
+
+def test_full_size_wide_rows_hash_properties(oracle):
+    """The bench shape 2^22 rows x 32 f64 columns, blowup 8, through the rows + leaves last pass (plan 8, 8, 6 for
+    32-column rows): size-independent properties instead of a full CPU run — LDE rows by Horner evaluation of the returned trace
+    polynomials, leaves by the oracle's hash of those rows, a Merkle path, and the root against the same commitment built with
+    the separate row-hash kernel (WF_ROWS_HASH_WIDE=0, the round-4 path that the suite holds against the oracle word for word)."""
+    import os
+    import torch
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd._lib import Context
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    n, c, b = 1 << 22, 32, 8
+    trace = ctx.to_device(np.random.default_rng(2232).integers(0, fields.M, (c, n), dtype=np.uint64))
+    ctx.prof_enable(True)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace.clone(), 1, ctx), prover.StarkDomain(n, b))
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    assert "ntt_pass_last_rows_hash" in prof and "hash_rows_blake3" not in prof, prof
+    N = n * b
+    hp = polys.to_host()
+    g = oracle.f64_root_of_unity(25)
+    pos = [0, 1, 9, 4095, N // 2 + 3, N - 1]
+    rows = lde.rows(pos)
+    for r, k in zip(rows, pos):
+        x = oracle.f64_mul(fields.new(7), oracle.f64_exp(g, k))
+        for col in (0, 7, 8, 31):
+            assert r[col] == oracle.poly_eval(hp[col], x), (k, col)
+    leaves = tree.leaves
+    for k, r in zip(pos, rows):
+        assert np.array_equal(leaves[k], oracle.hash_elements(0, r)), k
+    leaf, proof = tree.prove(4095)
+    crypto.MerkleTree.verify(crypto.Blake3_256, tree.root(), 4095, leaf, proof)
+    root = tree.root().copy()
+    del lde, tree, polys
+    torch.cuda.empty_cache()
+    os.environ["WF_ROWS_HASH_WIDE"] = "0"
+    try:
+        other = Context(ctx.device.index or 0)
+    finally:
+        del os.environ["WF_ROWS_HASH_WIDE"]
+    try:
+        _, tree2, _ = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace.clone(), 1, other), prover.StarkDomain(n, b))
+        assert np.array_equal(tree2.root(), root)
+        del tree2
+    finally:
+        other.sync()
+        other.close()

@@ -62,6 +62,19 @@ if want("lde_long"):
     lde_case("2^24x4_b8_f64_blake3", fields.f64, 24, 4)
 if want("config3"):
     lde_case("2^22x64_b8_f128_blake3_p8", fields.f128, 22, 64, parts=8)
+if want("lde_bench_widths"):
+    lde_case("2^19x64_b8_f64_blake3", fields.f64, 19, 64)
+    lde_case("2^19x96_b8_f64_blake3", fields.f64, 19, 96)
+if want("ntt_fields"):
+    for key, field, D in (("2^20_f128", fields.f128, 1), ("2^20_f62", fields.f62, 1), ("2^20_f64_quad", fields.f64, 2), ("2^20_f64_cubic", fields.f64, 3)):
+        if field is fields.f64:
+            d_ = ctx.to_device(rng.integers(0, fields.M, (1 << 20) * D, dtype=np.uint64))
+        elif field is fields.f128:
+            d_ = ctx.to_device(rng.integers(0, 1 << 62, (1 << 20) * D * 2, dtype=np.uint64))
+        else:
+            d_ = ctx.to_device(rng.integers(0, 1 << 61, (1 << 20) * D, dtype=np.uint64))
+        measure("ntt_" + key, lambda: fft.evaluate_poly(d_, ext_degree=D, field=field))
+        del d_
 if want("lde_rescue"):
     lde_case("2^20x4_b8_f64_rp64", fields.f64, 20, 4, hasher=crypto.Rp64_256)
 if want("merkle"):

@@ -3,7 +3,7 @@
 # Produces under gpurun_out/profiles/<round>/: the plain bench line, the rocprofv3 --kernel-trace --stats summary of the
 # same bench command, and the PMC summary (separate --pmc passes, no tracing options combined with them).
 set -u
-R=${1:-r04}
+R=${1:-r05}
 OUT=gpurun_out/profiles/$R
 RAW=gpurun_out/prof_raw_$R
 mkdir -p "$OUT" "$RAW"
@@ -21,6 +21,11 @@ cp "$RAW/kt/${R}_kernel_stats.csv" "$OUT/bench_kernel_stats.csv"
 rocprofv3 --pmc FETCH_SIZE -d "$RAW/pmc_fetch" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE -d "$RAW/pmc_write" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY SQ_WAIT_ANY -d "$RAW/pmc_sq" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+# where the waves' cycles go: LDS issue stalls, scalar instructions, vector-memory cycles, waves and busy time — three
+# more passes, so that one counter this build of rocprofv3 does not know cannot cost the others
+rocprofv3 --pmc SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_WAVES GRBM_GUI_ACTIVE -d "$RAW/pmc_sq2" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+rocprofv3 --pmc SQ_INST_CYCLES_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM -d "$RAW/pmc_sq3" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA -d "$RAW/pmc_sq4" -o $R --output-format csv -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
 python tools/summarize_pmc.py "$RAW" $R > "$OUT/bench_pmc_summary.json"
 # per-size kernel table of the traced bench run (the --stats summary averages a kernel over launches of very different sizes)
 python tools/kernel_trace_table.py "$RAW/kt/${R}_kernel_trace.csv" > "$OUT/bench_kernel_trace_by_size.csv"
