@@ -30,7 +30,7 @@ def make(**env):
 
 # r04 = the round-4 behaviour: three passes, wide rows hashed by the separate kernel
 ctxs = {"r04": make(WF_NTT_BIG="0", WF_ROWS_HASH_WIDE="0"), "two-pass": make(WF_NTT_BIG="1", WF_ROWS_HASH_WIDE="0"),
-        "rows+hash": make(WF_NTT_BIG="0"), "default": make()}
+        "rows+hash": make(WF_NTT_BIG="0"), "default": make(), "linear-order": make(WF_NTT_COSET_ORDER="0")}
 # spin the clocks up
 x = torch.from_numpy(np.random.default_rng(1).integers(0, 1 << 62, 1 << 24, dtype=np.int64)).to(base.device)
 t0 = time.perf_counter()
@@ -54,7 +54,7 @@ for log_n in (() if only else (20, 21, 22, 23, 24)):
     d = torch.from_numpy(np.random.default_rng(log_n).integers(0, 1 << 62, n, dtype=np.int64)).to(base.device)
     row = []
     for name, ctx in ctxs.items():
-        if name == "rows+hash":
+        if name in ("rows+hash", "linear-order"):
             continue
         for _ in range(3):
             fft.evaluate_poly(d, ctx=ctx)

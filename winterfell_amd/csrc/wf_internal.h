@@ -103,6 +103,9 @@ struct wf_ctx {
     // WF_ROWS_HASH_WIDE=0 (read once at context creation): rows wider than one 8-column group are hashed by the separate row-hash
     // kernel instead of the last NTT pass (A/B measurements)
     bool rows_hash_wide = true;
+    // WF_NTT_COSET_ORDER=0: the first pass of a coset LDE walks its tiles vector by vector (round 4) instead of running the cosets
+    // of a source tile side by side on one XCD
+    bool coset_order = true;
     // WF_NTT_PLAN, parsed once at context creation (context.hip): a pass plan for transforms of 2^plan_log_n points, 0 = none
     uint32_t plan_log_n = 0, plan_npass = 0, plan_log_r[6] = {0, 0, 0, 0, 0, 0};
 
