@@ -568,6 +568,9 @@ def main():
                             "issue_us_if_every_inst_were_fast": wave_insts * VALU_FAST_CYCLES / (1024 * ghz * 1e9) * 1e6,
                             "issue_us_if_every_inst_were_slow": wave_insts * VALU_SLOW_CYCLES / (1024 * ghz * 1e9) * 1e6,
                             "measured_us": fwd_us,
+                            # SQ_ACTIVE_INST_VALU counts one quad-cycle (4 clocks) per wave-instruction: the share of the kernels' SIMD
+                            # time in which the vector ALU is issuing.  Near 1 = bound by instruction issue, whatever the waves wait for.
+                            "valu_busy_frac_at_4_clocks_per_inst": wave_insts * 4.0 / (1024 * ghz * 1e9) / (fwd_us * 1e-6),
                             "stall_breakdown": stall_breakdown(stall),
                             "what": "SQ_INSTS_VALU (wave-instructions, summed over the transform's launches) priced at the two issue rates "
                                     "tools/microbench_isa.hip measures on this chip: %.1f cycles per wave-instruction on a SIMD for plain 32-bit "
@@ -582,11 +585,15 @@ def main():
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/%s/bench_pmc_summary.json)" % pmc_round,
             "valu": valu,
             "limiter": "VALU issue, not HBM: a pass executes ~90-115 wave-instructions per element (limb DFTs, two multiply-accumulate "
-                       "exits, the Montgomery chain of the twiddle progression; `valu` prices them).  Round 4's experiments (DESIGN.md "
-                       "section 5.R4): with the arithmetic removed the same loads, LDS exchange and stores take 24.5 us per pass (the 256 MiB "
-                       "working set is served by the Infinity Cache) against 59; the time is the same with 2, 3 or 4 workgroups per CU; it "
-                       "follows the instruction count linearly (12 us + 0.019 us per instruction of a lane's tile).  HBM traffic = 1.02x the "
-                       "data per pass, three passes (a two-pass radix-4096 plan does not fit LDS with 128-byte row segments)",
+                       "exits, the Montgomery chain of the twiddle progression; `valu` prices them).  Round 5's counters "
+                       "(profiles/r05/ntt_2p24_stall_counters.json, `valu.stall_breakdown`): a wave of a non-last pass is issuing 38 % of its "
+                       "cycles (33 % VALU), stalled at issue 27.5 % (LDS part 0.6 %) and parked on a wait or barrier 34 %; with three waves per "
+                       "SIMD that adds up to a vector ALU that issues in ~0.8-0.9 of the kernel's cycles (`valu_busy_frac_at_4_clocks_per_inst`): "
+                       "the issue stalls are the other waves' instructions, not a separate loss.  Round 4's experiments (DESIGN.md 5.R4): with "
+                       "the arithmetic removed the same loads, LDS exchange and stores take 24.5 us per pass (the working set is served by the "
+                       "Infinity Cache) against 59; the time follows the instruction count linearly.  A two-pass plan (three-step passes of radix "
+                       "4096, csrc/ntt_big.cuh) was built and measured in round 5: same instruction count, one 1024-lane workgroup per CU, "
+                       "229 us against 183-193 us at 2^24 (it wins at 2^21 / 2^22: -14 % / -9 %, and is the default there)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,

@@ -34,7 +34,8 @@ def _setup(oracle, example, fname, n, blowup):
 @pytest.mark.parametrize("example,fname,hname,n,D,grinding,queries", [
     ("fib_small", "f64", "Blake3_256", 1 << 10, 2, 8, 12), ("fib_small", "f64", "Blake3_256", 1 << 8, 1, 0, 5), ("fib_small", "f64", "Blake3_256", 1 << 9, 3, 12, 20),
     ("rescue", "f128", "Blake3_256", 1 << 9, 2, 8, 12), ("rescue", "f128", "Blake3_256", 1 << 8, 1, 16, 28), ("mulfib8", "f128", "Blake3_256", 1 << 8, 2, 4, 9),
-    ("vdf_exempt", "f128", "Blake3_192", 1 << 9, 1, 8, 12), ("fib_small", "f64", "Sha3_256", 1 << 8, 2, 6, 7)])
+    ("vdf_exempt", "f128", "Blake3_192", 1 << 9, 1, 8, 12), ("fib_small", "f64", "Sha3_256", 1 << 8, 2, 6, 7),
+    ("fib_small", "f64", "Rp64_256", 1 << 9, 2, 6, 9), ("fib_small", "f64", "Rp64_256", 1 << 8, 3, 0, 70), ("fib_small", "f64", "RpJive64_256", 1 << 8, 1, 4, 5)])
 def test_device_transcript_proof_equals_the_host_transcript_proof(oracle, example, fname, hname, n, D, grinding, queries):
     import winterfell_amd
     from winterfell_amd import crypto, prover
@@ -68,15 +69,32 @@ def test_device_transcript_proof_equals_the_host_transcript_proof(oracle, exampl
     assert dev.to_bytes() == host.to_bytes()
 
 
-def test_device_transcript_falls_back_where_it_does_not_apply(oracle):
-    """a hasher without a device coin (Rescue: a permutation on one lane costs more than the round trip) keeps the host transcript"""
+def test_device_transcript_with_a_rescue_coin(oracle):
+    """Rp64_256 (SURVEY D2 variant 3b: f64 + Rp64_256): the coin's steps run on 16-lane groups (csrc/coin.hip), so the whole transcript
+    stays on the device for the Rescue family too; the proof is the host-transcript proof byte for byte (which
+    tests/test_gpu_proof_artefacts.py holds against the in-repo CPU prover and the independent verifier)"""
     import winterfell_amd
     from winterfell_amd import crypto, prover
     ctx = winterfell_amd.default_context()
-    fld, trace, air, pub = _setup(oracle, "fib_small", "f64", 1 << 8, 8)
-    options = prover.ProofOptions(6, 8, 4, ext_degree=1, fri_folding_factor=4, fri_remainder_max_degree=7)
-    a = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, crypto.Rp64_256, pub, transcript="device")
-    b = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, crypto.Rp64_256, pub)
+    for hasher in (crypto.Rp64_256, crypto.RpJive64_256):
+        fld, trace, air, pub = _setup(oracle, "fib_small", "f64", 1 << 8, 8)
+        options = prover.ProofOptions(6, 8, 4, ext_degree=1, fri_folding_factor=4, fri_remainder_max_degree=7)
+        a = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, pub, transcript="device")
+        b = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, hasher, pub)
+        assert "queue_whole_transcript" in a.timings_ms and "queue_whole_transcript" not in b.timings_ms
+        assert a.pow_nonce == b.pow_nonce and a.query_positions == b.query_positions
+        assert a.to_bytes() == b.to_bytes()
+
+
+def test_device_transcript_falls_back_where_it_does_not_apply(oracle):
+    """a proof without FRI layers keeps the host transcript"""
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    ctx = winterfell_amd.default_context()
+    fld, trace, air, pub = _setup(oracle, "fib_small", "f64", 1 << 4, 8)
+    options = prover.ProofOptions(6, 8, 0, ext_degree=1, fri_folding_factor=4, fri_remainder_max_degree=127)
+    a = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, crypto.Blake3_256, pub, transcript="device")
+    b = prover.prove(air, prover.ColMatrix(trace, 1, ctx, fld), options, crypto.Blake3_256, pub)
     assert "queue_whole_transcript" not in a.timings_ms and a.to_bytes() == b.to_bytes()
 
 
@@ -90,7 +108,8 @@ def test_coin_grind_and_draw_integers_against_the_host_coin(oracle):
     from winterfell_amd.math import fields
     ctx = winterfell_amd.default_context()
     f = fields.f64
-    for hname, factor, nq, log_dom in (("Blake3_256", 10, 27, 20), ("Blake3_192", 6, 5, 9), ("Sha3_256", 8, 40, 33), ("Blake3_256", 0, 3, 4)):
+    for hname, factor, nq, log_dom in (("Blake3_256", 10, 27, 20), ("Blake3_192", 6, 5, 9), ("Sha3_256", 8, 40, 33), ("Blake3_256", 0, 3, 4),
+                                        ("Rp64_256", 6, 70, 20), ("RpJive64_256", 4, 5, 9)):
         hasher = getattr(crypto, hname)
         seed_elems = f.pack([f.new(v) for v in (3, 1, 4, 1, 5, 9, 2, 6)])
         host = crypto.DefaultRandomCoin(hasher, f, seed_elems, ctx)

@@ -150,7 +150,7 @@ def _bytes_to_elements(data, field, strict_index=True):
 class Rp64_256(_Hasher):
     """crypto::hash::Rp64_256 (crypto/src/hash/rescue/rp64_256/mod.rs:123-257)."""
     HASH_ID = WF_HASH_RP64_256
-    DEVICE_COIN = False
+    DEVICE_COIN = True      # round 5: the coin's steps run on 16-lane groups (csrc/coin.hip, rescue_coop.cuh), ~17 us each instead of 0.2 ms
 
     @classmethod
     def hash(cls, data, ctx=None):
@@ -178,7 +178,7 @@ class Rp62_248(_Hasher):
     """crypto::hash::Rp62_248 (crypto/src/hash/rescue/rp62_248/mod.rs:62-239): Rescue-Prime over f62; a digest is four
     f62 words (ElementDigest, digest.rs:16), serialised as 31 bytes."""
     HASH_ID = WF_HASH_RP62_248
-    DEVICE_COIN = False
+    DEVICE_COIN = True
 
     @classmethod
     def hash_elements(cls, elements, ctx=None, field=fields.f62):

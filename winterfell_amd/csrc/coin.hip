@@ -66,6 +66,152 @@ __global__ __launch_bounds__(64) void coin_reseed_draw_quad_kernel(CoinState *c,
     coin_reseed_draw_quad_wg<FIELD, D>(c, digest, root_out, out, threadIdx.x, msg, drawn, &ok_flag);
 }
 
+
+// ---- the Rescue family: a coin step on ONE lane is a whole permutation (~6400 dependent modular multiplications, 0.2 ms), which is
+// why round 4 kept the host transcript for these hashers.  Here a step runs on a 16-lane group with one state word per lane
+// (rescue_coop.cuh: the S-boxes lane-local, the MDS rows through LDS), ~17 us, and independent steps — the draws of one
+// wf_coin_draw, the query positions — on as many groups as there are steps.  crypto/src/random/default.rs:82-248.
+template <class C>
+__device__ __forceinline__ void coop_digest(uint64_t word, int i, volatile uint64_t *grp, uint32_t (&d)[8]) {
+    // the digest words sit on the group's output lanes: publish them (the group's exchange slots are free once the permutation has
+    // returned; one wavefront's DS operations execute in order) and let every lane of the group read all four
+    if (C::out_lane(i)) grp[C::out_word(i)] = word;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const uint64_t v = grp[w];
+        d[2 * w] = (uint32_t)v;
+        d[2 * w + 1] = (uint32_t)(v >> 32);
+    }
+}
+
+// sequential draws on one lane (the reference's loop, retries included): the fallback when an optimistic parallel draw met bytes
+// that do not decode (probability ~ count x 2^-32 for the 64-bit fields)
+template <class H, int FIELD, int D>
+__device__ __forceinline__ void coin_draw_lane(CoinState *c, const uint32_t (&seed)[8], uint64_t counter, uint32_t count, uint64_t *out) {
+    constexpr int WORDS = (FIELD == WF_FIELD_F128 ? 2 : 1) * D;
+    for (uint32_t k = 0; k < count; k++) {
+        bool ok = false;
+        for (int tries = 0; tries < 1000 && !ok; tries++) {
+            uint32_t d[8], b[8];
+            counter++;
+            H::merge_with_int(seed, counter, d);
+            H::as_bytes(d, b);
+            ok = coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS);
+        }
+        if (!ok) {
+            c->failed |= 1u;
+            break;
+        }
+    }
+    c->counter = counter;
+}
+
+#define WF_COOP_PROLOGUE                                                              \
+    typedef typename H::Coop C;                                                       \
+    const int i = threadIdx.x & (rcoop::GROUP - 1);                                   \
+    const int ii = i < C::S::W ? i : C::S::W - 1;                                     \
+    volatile uint64_t *grp = coop_lds + (threadIdx.x & ~(rcoop::GROUP - 1));
+
+// reseed: one group.  seed = merge(seed, digest), counter = 0
+template <class H>
+__global__ __launch_bounds__(16) void coin_reseed_coop_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out) {
+    __shared__ uint64_t coop_lds[16];
+    __shared__ uint64_t pair[8];
+    WF_COOP_PROLOGUE
+    if (i < 4) pair[i] = (uint64_t)c->seed[2 * i] | ((uint64_t)c->seed[2 * i + 1] << 32);
+    else if (i < 8) pair[i] = (uint64_t)digest[2 * (i - 4)] | ((uint64_t)digest[2 * (i - 4) + 1] << 32);
+    if (root_out && i < 8) root_out[i] = digest[i];
+    __syncthreads();
+    uint32_t d[8];
+    coop_digest<C>(C::merge(pair, i, ii, grp), i, grp, d);
+    if (i < 8) c->seed[i] = d[i];
+    if (i == 0) c->counter = 0;
+}
+
+// draw::<E>() `count` times: draw k = next() with counter0 + 1 + k, every group one draw at a time, all of them at once — valid when
+// every draw decodes at its first try; if one does not, lane 0 redoes the whole request in the reference's order
+template <class H, int FIELD, int D>
+__global__ __launch_bounds__(1024) void coin_draw_coop_kernel(CoinState *c, uint32_t count, uint64_t *out) {
+    constexpr int WORDS = (FIELD == WF_FIELD_F128 ? 2 : 1) * D;
+    __shared__ uint64_t coop_lds[1024];
+    __shared__ int bad;
+    WF_COOP_PROLOGUE
+    const uint32_t g = threadIdx.x / rcoop::GROUP, ng = blockDim.x / rcoop::GROUP;
+    uint32_t seed[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) seed[w] = c->seed[w];
+    const uint64_t counter0 = c->counter;
+    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();
+    for (uint32_t k = g; k < count; k += ng) {
+        uint32_t d[8], b[8];
+        coop_digest<C>(C::merge_with_int(seed, counter0 + 1 + k, i, ii, grp), i, grp, d);
+        if (i == 0) {
+            H::as_bytes(d, b);
+            if (!coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS)) bad = 1;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (bad) coin_draw_lane<H, FIELD, D>(c, seed, counter0, count, out);
+        else c->counter = counter0 + count;
+    }
+}
+
+// commit_fri_layer + draw_fri_alpha: reseed, then one draw, on one group
+template <class H, int FIELD, int D>
+__global__ __launch_bounds__(16) void coin_reseed_draw_coop_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out, uint64_t *out) {
+    __shared__ uint64_t coop_lds[16];
+    __shared__ uint64_t pair[8];
+    WF_COOP_PROLOGUE
+    if (i < 4) pair[i] = (uint64_t)c->seed[2 * i] | ((uint64_t)c->seed[2 * i + 1] << 32);
+    else if (i < 8) pair[i] = (uint64_t)digest[2 * (i - 4)] | ((uint64_t)digest[2 * (i - 4) + 1] << 32);
+    if (root_out && i < 8) root_out[i] = digest[i];
+    __syncthreads();
+    uint32_t seed[8], d[8], b[8];
+    coop_digest<C>(C::merge(pair, i, ii, grp), i, grp, seed);
+    if (i < 8) c->seed[i] = seed[i];
+    coop_digest<C>(C::merge_with_int(seed, 1, i, ii, grp), i, grp, d);
+    if (i == 0) {
+        H::as_bytes(d, b);
+        if (coin_element<FIELD, D>(b, out)) c->counter = 1;
+        else coin_draw_lane<H, FIELD, D>(c, seed, 0, 1, out);
+    }
+}
+
+// draw_integers: the new seed on group 0, then one value per group
+template <class H>
+__global__ __launch_bounds__(1024) void coin_draw_integers_coop_kernel(CoinState *c, const unsigned long long *nonce, uint32_t num_values, uint64_t mask,
+                                                                       uint64_t *out) {
+    __shared__ uint64_t coop_lds[1024];
+    __shared__ uint32_t ns[8];
+    WF_COOP_PROLOGUE
+    const uint32_t g = threadIdx.x / rcoop::GROUP, ng = blockDim.x / rcoop::GROUP;
+    if (g == 0) {
+        uint32_t seed[8], d[8];
+#pragma unroll
+        for (int w = 0; w < 8; w++) seed[w] = c->seed[w];
+        coop_digest<C>(C::merge_with_int(seed, (uint64_t)*nonce, i, ii, grp), i, grp, d);
+        if (i < 8) ns[i] = d[i];
+    }
+    __syncthreads();
+    uint32_t seed[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) seed[w] = ns[w];
+    for (uint32_t v = g; v < num_values; v += ng) {
+        uint32_t d[8], b[8];
+        coop_digest<C>(C::merge_with_int(seed, (uint64_t)v + 1, i, ii, grp), i, grp, d);
+        if (i == 0) {
+            H::as_bytes(d, b);
+            out[v] = ((uint64_t)b[0] | ((uint64_t)b[1] << 32)) & mask;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < 8) c->seed[threadIdx.x] = ns[threadIdx.x];
+    if (threadIdx.x == 0) c->counter = num_values;
+}
+#undef WF_COOP_PROLOGUE
+
 template <class H>
 int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, const uint32_t *dg, uint32_t *cp, uint64_t *o) {
     if constexpr (H::QUAD_MERGE) {
@@ -81,6 +227,23 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
             return WF_OK;
         }
 #undef WF_RQ
+    }
+    if constexpr (H::COOP) {
+#define WF_RC(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16), 0, ctx->stream, c, dg, cp, o)
+        if (field == WF_FIELD_F128) {
+            if (D == 1) WF_RC(WF_FIELD_F128, 1);
+            else WF_RC(WF_FIELD_F128, 2);
+        } else if (field == WF_FIELD_F64) {
+            if (D == 1) WF_RC(WF_FIELD_F64, 1);
+            else if (D == 2) WF_RC(WF_FIELD_F64, 2);
+            else WF_RC(WF_FIELD_F64, 3);
+        } else {
+            if (D == 1) WF_RC(WF_FIELD_F62, 1);
+            else if (D == 2) WF_RC(WF_FIELD_F62, 2);
+            else WF_RC(WF_FIELD_F62, 3);
+        }
+#undef WF_RC
+        return WF_OK;
     }
 #define WF_RD(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_kernel<H, FIELD, DEG>), dim3(1), dim3(1), 0, ctx->stream, c, dg, cp, o)
     if (field == WF_FIELD_F128) {
@@ -101,6 +264,25 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
 
 template <class H>
 int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t count, uint64_t *o) {
+    if constexpr (H::COOP) {
+        // as many 16-lane groups as draws, up to the 64 of one 1024-lane workgroup
+        const uint32_t groups = count < 64 ? count : 64;
+#define WF_DC(FIELD, DEG) hipLaunchKernelGGL((coin_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16 * groups), 0, ctx->stream, c, count, o)
+        if (field == WF_FIELD_F128) {
+            if (D == 1) WF_DC(WF_FIELD_F128, 1);
+            else WF_DC(WF_FIELD_F128, 2);
+        } else if (field == WF_FIELD_F64) {
+            if (D == 1) WF_DC(WF_FIELD_F64, 1);
+            else if (D == 2) WF_DC(WF_FIELD_F64, 2);
+            else WF_DC(WF_FIELD_F64, 3);
+        } else {
+            if (D == 1) WF_DC(WF_FIELD_F62, 1);
+            else if (D == 2) WF_DC(WF_FIELD_F62, 2);
+            else WF_DC(WF_FIELD_F62, 3);
+        }
+#undef WF_DC
+        return WF_OK;
+    }
 #define WF_DRAW(FIELD, DEG) hipLaunchKernelGGL((coin_draw_kernel<H, FIELD, DEG>), dim3(1), dim3(1), 0, ctx->stream, c, count, o)
     if (field == WF_FIELD_F128) {
         if (D == 1) WF_DRAW(WF_FIELD_F128, 1);
@@ -216,8 +398,15 @@ extern "C" int wf_coin_draw_integers(wf_ctx *ctx, int hash, void *d_coin, const 
     WF_TRY(check_hash(hash));
     wf_prof_begin(ctx, "coin");
     WF_TRY(with_hasher(hash, [&](auto h) {
-        hipLaunchKernelGGL(coin_draw_integers_kernel<decltype(h)>, dim3(1), dim3(256), 0, ctx->stream, (CoinState *)d_coin,
-                           (const unsigned long long *)d_nonce, num_values, (1ull << log_domain_size) - 1, (uint64_t *)d_out);
+        typedef decltype(h) H;
+        if constexpr (H::COOP) {
+            const uint32_t groups = num_values < 64 ? num_values : 64;
+            hipLaunchKernelGGL(coin_draw_integers_coop_kernel<H>, dim3(1), dim3(16 * groups), 0, ctx->stream, (CoinState *)d_coin,
+                               (const unsigned long long *)d_nonce, num_values, (1ull << log_domain_size) - 1, (uint64_t *)d_out);
+        } else {
+            hipLaunchKernelGGL(coin_draw_integers_kernel<H>, dim3(1), dim3(256), 0, ctx->stream, (CoinState *)d_coin,
+                               (const unsigned long long *)d_nonce, num_values, (1ull << log_domain_size) - 1, (uint64_t *)d_out);
+        }
         return (int)WF_OK;
     }));
     wf_prof_end(ctx);
@@ -242,8 +431,13 @@ extern "C" int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d
     WF_TRY(check_hash(hash));
     wf_prof_begin(ctx, "coin");
     WF_TRY(with_hasher(hash, [&](auto h) {
-        hipLaunchKernelGGL(coin_reseed_kernel<decltype(h)>, dim3(1), dim3(1), 0, ctx->stream, (CoinState *)d_coin, (const uint32_t *)d_digest,
-                           (uint32_t *)d_digest_copy);
+        typedef decltype(h) H;
+        if constexpr (H::COOP)
+            hipLaunchKernelGGL(coin_reseed_coop_kernel<H>, dim3(1), dim3(16), 0, ctx->stream, (CoinState *)d_coin, (const uint32_t *)d_digest,
+                               (uint32_t *)d_digest_copy);
+        else
+            hipLaunchKernelGGL(coin_reseed_kernel<H>, dim3(1), dim3(1), 0, ctx->stream, (CoinState *)d_coin, (const uint32_t *)d_digest,
+                               (uint32_t *)d_digest_copy);
         return (int)WF_OK;
     }));
     wf_prof_end(ctx);
