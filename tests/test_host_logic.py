@@ -229,3 +229,22 @@ def test_three_step_ntt_passes_emulated_on_the_host(tmp_path):
     out = subprocess.run([exe, "21"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stdout + out.stderr
     assert out.stdout.strip().endswith("all ok")
+
+
+def test_f128_table_product_on_the_host(tmp_path):
+    """winterfell_amd/csrc/f128.cuh compiled for the host: mul (two folds of the 256-bit product) and mul_tab (round 5: a table
+    twiddle as the pair (w, w 2^64), a_lo w + a_hi (w 2^64), one fold) against an independent double-and-add modulo
+    p = 2^128 - 45 * 2^40 + 1, 200 000 random products and the edge values (math/src/field/f128/mod.rs:429-466)."""
+    import shutil
+    import subprocess
+    clang = "/opt/rocm/lib/llvm/bin/clang++"
+    if not os.path.exists(clang):
+        clang = shutil.which("clang++")
+    if not clang:
+        pytest.skip("no clang++")
+    exe = str(tmp_path / "f128_host_test")
+    subprocess.check_call([clang, "-O2", "-std=c++17", "-I", os.path.join(ROOT, "tests", "cpp", "stub"),
+                           os.path.join(ROOT, "tests", "cpp", "f128_host_test.cpp"), "-o", exe])
+    out = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "mul and mul_tab ok" in out.stdout

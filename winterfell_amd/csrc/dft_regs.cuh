@@ -12,7 +12,8 @@ __host__ __device__ constexpr int brev(int i, int bits) {
 
 // In-register decimation-in-frequency DFT of N = 2^LOGN points; X[k] ends up in x[brev(k)].
 // w16: the field's omega_16^j table (unused by fields whose small roots are powers of two).
-template <class F, int LOGN>
+// TAB: w16 is in the field's NTT table layout (F::TAB_WORDS words per entry, F::mul_w16_tab) instead of one word per entry.
+template <class F, int LOGN, bool TAB = false>
 __device__ __forceinline__ void dft_dif(typename F::T (&x)[1 << LOGN], const typename F::T *w16) {
     typedef typename F::T T;
     constexpr int N = 1 << LOGN;
@@ -26,7 +27,7 @@ __device__ __forceinline__ void dft_dif(typename F::T (&x)[1 << LOGN], const typ
                 const T u = x[blk + i], v = x[blk + i + half];
                 x[blk + i] = F::add(u, v);
                 // twiddle omega_{2*half}^i = omega_16^(i * 8 / half)
-                x[blk + i + half] = F::mul_w16(F::sub(u, v), (i * 8) / half, w16);
+                x[blk + i + half] = TAB ? F::mul_w16_tab(F::sub(u, v), (i * 8) / half, w16) : F::mul_w16(F::sub(u, v), (i * 8) / half, w16);
             }
         }
     }

@@ -29,6 +29,10 @@ struct F64 {
     static __device__ __forceinline__ T zero() { return 0; }
     static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
     static __device__ __forceinline__ T load_norm(T a) { return a; }   // memory words are always canonical
+    // NTT pass tables (omega_256^e, omega_16^j, small inter-pass tables): one word per entry
+    static constexpr int TAB_WORDS = 1;
+    static __device__ __forceinline__ T mul_tab(T v, const T *tab, uint64_t idx) { return gl::mul(v, tab[idx]); }
+    static __device__ __forceinline__ T mul_w16_tab(T v, int j, const T *w) { return mul_w16(v, j, w); }
     static __device__ __forceinline__ T mul_w16(T v, int j, const T *) {
         switch (j) {
             case 0: return v;
@@ -62,6 +66,16 @@ struct F128 {
     static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
     static __device__ __forceinline__ T load_norm(T a) { return a; }
     static __device__ __forceinline__ T mul_w16(T v, int j, const T *w16) { return j == 0 ? v : f128::mul(v, w16[j]); }
+    // NTT pass tables hold PAIRS (w, w * 2^64 mod p): a product with a table entry is a_lo w + a_hi (w 2^64), one fold instead of the
+    // two of a 256-bit product (f128::mul_tab: ~65 instead of ~78 instructions; round 5)
+    static constexpr int TAB_WORDS = 2;
+#ifndef F128_PLAIN_TABLE_MUL
+    static __device__ __forceinline__ T mul_tab(T v, const T *tab, uint64_t idx) { return f128::mul_tab(v, tab[2 * idx], tab[2 * idx + 1]); }
+    static __device__ __forceinline__ T mul_w16_tab(T v, int j, const T *w16) { return j == 0 ? v : f128::mul_tab(v, w16[2 * j], w16[2 * j + 1]); }
+#else   // A/B builds (tools/build_variant.sh): the same tables, the general product on the first word of a pair
+    static __device__ __forceinline__ T mul_tab(T v, const T *tab, uint64_t idx) { return f128::mul(v, tab[2 * idx]); }
+    static __device__ __forceinline__ T mul_w16_tab(T v, int j, const T *w16) { return j == 0 ? v : f128::mul(v, w16[2 * j]); }
+#endif
     // quadratic extension x^2 - x - 1 (f128/mod.rs:267-272)
     template <int D>
     static __device__ __forceinline__ void ext_mul(const T (&a)[D], const T (&b)[D], T (&o)[D]) {
@@ -106,6 +120,9 @@ struct F62 {
     static __device__ __forceinline__ bool is_zero(T a) { return a == 0; }
     static __device__ __forceinline__ T load_norm(T a) { return f62::norm(a); }   // accept the reference's lazy [0, 2M) words
     static __device__ __forceinline__ T mul_w16(T v, int j, const T *w16) { return j == 0 ? v : f62::mul(v, w16[j]); }
+    static constexpr int TAB_WORDS = 1;
+    static __device__ __forceinline__ T mul_tab(T v, const T *tab, uint64_t idx) { return f62::mul(v, tab[idx]); }
+    static __device__ __forceinline__ T mul_w16_tab(T v, int j, const T *w) { return mul_w16(v, j, w); }
     template <int D>
     static __device__ __forceinline__ void ext_mul(const T (&a)[D], const T (&b)[D], T (&o)[D]) {
         if constexpr (D == 1) {

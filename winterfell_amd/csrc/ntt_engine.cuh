@@ -319,14 +319,14 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                 }
             }
         } else {
-        dft_dif<F, LOG_A>(x, p.w16);
+        dft_dif<F, LOG_A, true>(x, p.w16);
         if (B > 1) {
             // intra-pass twiddle omega_R^(k_a * b) = omega_256^((k_a * b) << (8 - LOG_R)), then LDS exchange
 #pragma unroll
             for (int i = 0; i < A; i++) {
                 const int ka = brev(i, LOG_A);
                 T val = x[i];
-                if (ka != 0 || (LAST && p.scale_in_w256)) val = F::mul(val, p.w256[(uint32_t)(ka * b1) << (8 - LOG_R)]);
+                if (ka != 0 || (LAST && p.scale_in_w256)) val = F::mul_tab(val, p.w256, (uint32_t)(ka * b1) << (8 - LOG_R));
                 if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
                 else lds[idx_l(ka, t1, b1)] = val;
             }
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         if constexpr (!LAST) {
             o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
             o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
-            if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 ? 4 : 1) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
+            if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 ? 4 : (p.tw_pair ? F::TAB_WORDS : 1)) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
         } else if (RM || (RH && p.rh_log_cp > 3)) {
             // LDE row u + b * m, column bc
             o_ptr = o_ptr0 = p.dst + (u2 + ((c + ncols * (uint64_t)kbase) << p.rm_log_b)) * p.rm_row_width + bc2;
@@ -463,7 +463,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int ip = 0; ip < CNT; ip++) {
                 const int i = brev(ip, LOG_CNT);                 // register holding output digit k0 + step_k * ip
-                *out_next(ip == 0, (int64_t)step_k * o_step) = F::mul(val(i), tw0[((uint64_t)(step_k * (uint32_t)ip)) << log_s]);
+                const uint64_t ti = ((uint64_t)(step_k * (uint32_t)ip)) << log_s;
+                // small tables are in the field's table layout (f128: pairs, F::mul_tab), the big shared ones one word per entry
+                *out_next(ip == 0, (int64_t)step_k * o_step) = (F::TAB_WORDS > 1 && p.tw_pair) ? F::mul_tab(val(i), tw0, ti) : F::mul(val(i), tw0[ti]);
             }
             return;
         }
@@ -555,7 +557,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                     }
                 }
             } else {
-                dft_dif<F, LOG_B>(y, p.w16);
+                dft_dif<F, LOG_B, true>(y, p.w16);
                 if constexpr (!LAST) {
                     emit_progression([&](int i) { return y[i]; }, (uint32_t)ka, (uint32_t)A, std::integral_constant<int, LOG_B>{});
                 } else {
@@ -751,7 +753,8 @@ static bool rows_mode_ok(uint32_t L, uint32_t log_b, uint32_t base_cols) {
 namespace {
 template <class F>
 __global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename F::T *w_lo, const typename F::T *w_hi, uint32_t w_log_lo,
-                                                                 uint32_t log_s, uint32_t log_mult, uint32_t log_total, typename F::T *out) {
+                                                                 uint32_t log_s, uint32_t log_mult, uint32_t log_total, typename F::T *out, uint32_t pair,
+                                                                 typename F::T two64) {
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >> log_total) return;
     const uint32_t kp = idx >> log_s, rem = idx & ((1u << log_s) - 1);
@@ -764,7 +767,12 @@ __global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename 
         out[4 * (uint64_t)idx + 2] = gl::mul_pow2<48>(c);
         out[4 * (uint64_t)idx + 3] = gl::mul_pow2<72>(c);
     } else {
-        out[idx] = w;
+        if (F::TAB_WORDS > 1 && pair) {      // (w, w * 2^64): F::mul_tab
+            out[2 * (uint64_t)idx] = w;
+            out[2 * (uint64_t)idx + 1] = F::mul(w, two64);
+        } else {
+            out[idx] = w;
+        }
     }
 }
 }  // namespace
@@ -772,11 +780,16 @@ __global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename 
 #ifndef NTT_TW_TABLE_BATCH_MAX_LOG
 #define NTT_TW_TABLE_BATCH_MAX_LOG 22   // the same for transforms of >= 8 vectors at a time (f128: 64 MiB): the table is shared by all of them
 #endif
+#ifndef NTT_TW_PAIR_MAX_LOG
+#define NTT_TW_PAIR_MAX_LOG 17          // f128: tables of up to 2^17 entries are kept as pairs (w, w 2^64) for F::mul_tab: 4 MiB, L2 resident
+#endif
 template <class HF>
-static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uint32_t r, uint32_t log_s, uint32_t log_mult, uint32_t nvec, const void **out) {
+static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uint32_t r, uint32_t log_s, uint32_t log_mult, uint32_t nvec, const void **out,
+                             uint32_t *pair_out) {
     typedef typename HF::Dev F;
     typedef typename F::T T;
     *out = nullptr;
+    *pair_out = 0;
     const uint32_t log_total = r + log_s;
     // f64 keeps four words per twiddle (l24.cuh): the same byte budget is one entry-doubling earlier; single-step passes
     // (radix 2) have no limb form of the table multiplication
@@ -793,19 +806,22 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
 #ifndef NTT_F64_TW_TABLES
     if (F::USE_L24) return WF_OK;
 #endif
+    const uint32_t pair = (F::TAB_WORDS > 1 && log_total <= NTT_TW_PAIR_MAX_LOG) ? 1u : 0u;      // a function of the key
     auto key = std::make_tuple((int)F::ID, L, r, log_s, log_mult);
     auto it = ctx->pass_twiddles.find(key);
     if (it == ctx->pass_twiddles.end()) {
         void *d;
-        WF_TRY(wf_dev_malloc(ctx, &d, (sizeof(T) * (F::USE_L24 ? 4 : 1)) << log_total));
+        WF_TRY(wf_dev_malloc(ctx, &d, (sizeof(T) * (F::USE_L24 ? 4 : (pair ? F::TAB_WORDS : 1))) << log_total));
         ctx->owned.push_back(d);
         const uint32_t total = 1u << log_total;
+        const T two64 = HF::to_internal(HF::mulmod(HF::from_u64(1ull << 32), HF::from_u64(1ull << 32)));
         hipLaunchKernelGGL(pass_twiddle_table_kernel<F>, dim3((total + 255) / 256), dim3(256), 0, ctx->stream, (const T *)om.d_lo, (const T *)om.d_hi,
-                           om.log_lo, log_s, log_mult, log_total, (T *)d);
+                           om.log_lo, log_s, log_mult, log_total, (T *)d, pair, two64);
         WF_HIP(hipGetLastError());
         it = ctx->pass_twiddles.emplace(key, d).first;
     }
     *out = it->second;
+    *pair_out = pair;
     return WF_OK;
 }
 
@@ -885,7 +901,8 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     p.w_hi = (const T *)om.d_hi;
     p.w_log_lo = om.log_lo;
     void *w256, *w16;
-    WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16));
+    if constexpr (F::TAB_WORDS > 1) WF_TRY(wf_get_pair_tables<HF>(ctx, HF::from_u64(1), &w256, &w16));
+    else WF_TRY(wf_get_small_tables<HF>(ctx, &w256, &w16));
     if constexpr (F::USE_L24) WF_TRY(wf_get_w256_4form<HF>(ctx, HF::from_u64(1), &w256));
     p.w256 = (const T *)w256;
     p.w16 = (const T *)w16;
@@ -978,7 +995,10 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         if (last && job.has_post_const && log_b_for(r) > 0) {
             void *ws;
             if constexpr (F::USE_L24) WF_TRY(wf_get_w256_4form<HF>(ctx, HF::from_internal(p.post_const), &ws));
-            else WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
+            else if constexpr (F::TAB_WORDS > 1) {
+                void *unused;
+                WF_TRY(wf_get_pair_tables<HF>(ctx, HF::from_internal(p.post_const), &ws, &unused));
+            } else WF_TRY(wf_get_scaled_w256<HF>(ctx, HF::from_internal(p.post_const), &ws));
             p.w256 = (const T *)ws;
             p.scale_in_w256 = 1;
         }
@@ -1023,11 +1043,12 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             pf = resident > 0 && blocks >= 4ull * resident;
         }
         p.tw_tab = nullptr;
+        p.tw_pair = 0;
         if (!last && !pf) {
             uint32_t log_s = L;
             for (uint32_t qq = 0; qq <= q; qq++) log_s -= p.log_r[qq];
             const void *tab;
-            WF_TRY(get_pass_twiddles<HF>(ctx, om, L, r, log_s, L - log_s - r, job.nvec, &tab));
+            WF_TRY(get_pass_twiddles<HF>(ctx, om, L, r, log_s, L - log_s - r, job.nvec, &tab, &p.tw_pair));
             p.tw_tab = (const T *)tab;
         }
         auto k = kernel_for<F>(r, last, p.tw_tab != nullptr, pf, rh_pass);

@@ -30,6 +30,7 @@ struct PassParams {
     uint32_t has_post_const;
     T post_const;
     const T *tw_tab;          // non-last pass: inter-pass twiddles T[k'][rem] when the table is small (else nullptr: progression)
+    uint32_t tw_pair;         // tw_tab is in the field's table layout (F::TAB_WORDS words per entry: f128 pairs), small tables only
     uint32_t scale_in_w256;   // last pass of an inverse transform: w256 already carries the 1/n (applied for k_a = 0 too)
     // row-major output mode of the last pass (NttJob::rowmajor)
     uint32_t rowmajor, rm_log_b, rm_log_i, rm_base_cols;

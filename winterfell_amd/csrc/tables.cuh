@@ -109,6 +109,40 @@ static int wf_get_scaled_w256(wf_ctx *ctx, typename HF::T c, void **out) {
     return WF_OK;
 }
 
+// NTT pass tables of a field whose table products take PAIRS (F::TAB_WORDS = 2, f128): entry e of w256 = (c omega_256^e, c omega_256^e 2^64),
+// entry j of w16 = (omega_16^j, omega_16^j 2^64); c canonical (1 for the plain twiddles, 1/n for the last pass of an inverse transform)
+template <class HF>
+static int wf_get_pair_tables(wf_ctx *ctx, typename HF::T c, void **w256, void **w16) {
+    typedef typename HF::T T;
+    uint64_t c0, c1;
+    split128(c, c0, c1);
+    const auto key = std::make_tuple((int)HF::Dev::ID, c0, c1);
+    auto it = ctx->pair_tables.find(key);
+    if (it == ctx->pair_tables.end()) {
+        std::vector<T> h(512), g(16);
+        const T w = HF::root_of_unity(8), two64 = HF::from_u64(1ull << 32);
+        const T t64 = HF::mulmod(two64, two64);
+        T cur = c, plain = HF::from_u64(1);
+        for (int i = 0; i < 256; i++) {
+            h[2 * i] = HF::to_internal(cur);
+            h[2 * i + 1] = HF::to_internal(HF::mulmod(cur, t64));
+            if (i % 16 == 0 && i / 16 < 8) {                         // omega_16^j = omega_256^(16 j), never scaled
+                g[2 * (i / 16)] = HF::to_internal(plain);
+                g[2 * (i / 16) + 1] = HF::to_internal(HF::mulmod(plain, t64));
+            }
+            cur = HF::mulmod(cur, w);
+            plain = HF::mulmod(plain, w);
+        }
+        void *p256, *p16;
+        WF_TRY(wf_upload(ctx, h, &p256));
+        WF_TRY(wf_upload(ctx, g, &p16));
+        it = ctx->pair_tables.emplace(key, std::make_pair(p256, p16)).first;
+    }
+    *w256 = it->second.first;
+    *w16 = it->second.second;
+    return WF_OK;
+}
+
 // f64 passes (l24.cuh): rows of four plain-integer words  c * omega_256^e * T^k mod p,  k < 4, T = 2^24, e < 256 (c canonical;
 // c = 1 for the plain intra-pass twiddles, 1/n for the last pass of an inverse transform)
 template <class HF>

@@ -60,6 +60,8 @@ struct wf_ctx {
     std::map<std::tuple<int, uint64_t, uint64_t>, void *> w256_scaled;
     // the same for the f64 limb passes: rows of four words c * omega_256^e * 2^(24 k) mod p (plain integers), key (field, c, 0)
     std::map<std::tuple<int, uint64_t, uint64_t>, void *> w256_4form;
+    // NTT pass tables in pair form (f128: (w, w 2^64), tables.cuh wf_get_pair_tables), key (field, c): (w256, w16)
+    std::map<std::tuple<int, uint64_t, uint64_t>, std::pair<void *, void *>> pair_tables;
     // inter-pass twiddle tables T[k'][rem] = omega_n^((k' * rem) << log_mult) of the passes whose table is small enough to live in L2;
     // key (field, log_n, log_r of the pass, log_s, log_mult)
     std::map<std::tuple<int, uint32_t, uint32_t, uint32_t, uint32_t>, void *> pass_twiddles;
