@@ -5,7 +5,7 @@
 set -u
 R=${1:-r05}
 OUT=gpurun_out/profiles/$R
-RAW=gpurun_out/prof_raw_$R
+RAW=/tmp/prof_raw_$R      # raw rocprofv3 output stays on the box (gpurun_out/ is copied back only up to 64 MiB)
 mkdir -p "$OUT" "$RAW"
 export TMPDIR=/tmp
 # HBM bytes per call of the workloads behind bench.py's `rooflines` (LDE + commit shapes, Merkle, FRI), counters in separate runs

@@ -67,6 +67,9 @@ __global__ __launch_bounds__(64) void coin_reseed_draw_quad_kernel(CoinState *c,
 }
 
 
+#ifndef WF_COOP_COIN
+#define WF_COOP_COIN 1       // 0: the Rescue coin on one lane as in round 4 (A/B builds)
+#endif
 // ---- the Rescue family: a coin step on ONE lane is a whole permutation (~6400 dependent modular multiplications, 0.2 ms), which is
 // why round 4 kept the host transcript for these hashers.  Here a step runs on a 16-lane group with one state word per lane
 // (rescue_coop.cuh: the S-boxes lane-local, the MDS rows through LDS), ~17 us, and independent steps — the draws of one
@@ -228,7 +231,7 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
         }
 #undef WF_RQ
     }
-    if constexpr (H::COOP) {
+    if constexpr (H::COOP && WF_COOP_COIN != 0) {
 #define WF_RC(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16), 0, ctx->stream, c, dg, cp, o)
         if (field == WF_FIELD_F128) {
             if (D == 1) WF_RC(WF_FIELD_F128, 1);
@@ -264,7 +267,7 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
 
 template <class H>
 int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t count, uint64_t *o) {
-    if constexpr (H::COOP) {
+    if constexpr (H::COOP && WF_COOP_COIN != 0) {
         // as many 16-lane groups as draws, up to the 64 of one 1024-lane workgroup
         const uint32_t groups = count < 64 ? count : 64;
 #define WF_DC(FIELD, DEG) hipLaunchKernelGGL((coin_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16 * groups), 0, ctx->stream, c, count, o)
@@ -399,7 +402,7 @@ extern "C" int wf_coin_draw_integers(wf_ctx *ctx, int hash, void *d_coin, const 
     wf_prof_begin(ctx, "coin");
     WF_TRY(with_hasher(hash, [&](auto h) {
         typedef decltype(h) H;
-        if constexpr (H::COOP) {
+        if constexpr (H::COOP && WF_COOP_COIN != 0) {
             const uint32_t groups = num_values < 64 ? num_values : 64;
             hipLaunchKernelGGL(coin_draw_integers_coop_kernel<H>, dim3(1), dim3(16 * groups), 0, ctx->stream, (CoinState *)d_coin,
                                (const unsigned long long *)d_nonce, num_values, (1ull << log_domain_size) - 1, (uint64_t *)d_out);
@@ -432,7 +435,7 @@ extern "C" int wf_coin_reseed(wf_ctx *ctx, int hash, void *d_coin, const void *d
     wf_prof_begin(ctx, "coin");
     WF_TRY(with_hasher(hash, [&](auto h) {
         typedef decltype(h) H;
-        if constexpr (H::COOP)
+        if constexpr (H::COOP && WF_COOP_COIN != 0)
             hipLaunchKernelGGL(coin_reseed_coop_kernel<H>, dim3(1), dim3(16), 0, ctx->stream, (CoinState *)d_coin, (const uint32_t *)d_digest,
                                (uint32_t *)d_digest_copy);
         else
