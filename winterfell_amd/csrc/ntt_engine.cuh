@@ -41,6 +41,12 @@
 
 namespace {
 
+// At least four waves per SIMD (at most 128 VGPRs): the f64 radix-256 progression pass compiles to 129 on its own — three waves — and
+// fits 128 without a spill when asked (round 5, same box, alternating runs: 57.1-58.4 against 58.7-60.2 us per pass at 2^24; every
+// other pass kernel is below 128 already and keeps its own count).  -DNTT_WAVES_PER_EU=k pins the occupancy for experiments.
+#ifndef NTT_MIN_WAVES
+#define NTT_MIN_WAVES 4
+#endif
 #ifndef NTT_WAVES_PER_EU
 #define NTT_WAVES_ATTR
 #else
@@ -69,7 +75,7 @@ namespace {
 // stores the digest and the 64-byte padded row.  The coset-major round trip (write + read of the whole LDE) and the separate
 // transpose + hash launch disappear (2^20 x 4 x blowup 8: lde_transpose_hash 277 us + last pass 120 us -> one launch).
 template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false>
-__global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : 1))) void ntt_pass(PassParams<typename F::T> p) {
+__global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : (F::USE_L24 ? NTT_MIN_WAVES : 1)))) void ntt_pass(PassParams<typename F::T> p) {
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
     static_assert(!RH || (LAST && !PF && F::USE_L24 && LOG_B >= 3), "rows mode: f64 last passes of radix 64 / 128 / 256");
     static_assert(!(PF && TWTAB), "the table kernel's step-2 loads would drain the prefetch (in-order vm counter)");
