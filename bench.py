@@ -585,15 +585,15 @@ def main():
             "traffic": traffic, "traffic_unit": "HBM bytes per transform (rocprofv3 PMC, profiles/%s/bench_pmc_summary.json)" % pmc_round,
             "valu": valu,
             "limiter": "VALU issue, not HBM: a pass executes ~90-115 wave-instructions per element (limb DFTs, two multiply-accumulate "
-                       "exits, the Montgomery chain of the twiddle progression; `valu` prices them).  Round 5's counters "
-                       "(profiles/r05/ntt_2p24_stall_counters.json, `valu.stall_breakdown`): a wave of a non-last pass is issuing 38 % of its "
-                       "cycles (33 % VALU), stalled at issue 27.5 % (LDS part 0.6 %) and parked on a wait or barrier 34 %; with three waves per "
-                       "SIMD that adds up to a vector ALU that issues in ~0.8-0.9 of the kernel's cycles (`valu_busy_frac_at_4_clocks_per_inst`): "
-                       "the issue stalls are the other waves' instructions, not a separate loss.  Round 4's experiments (DESIGN.md 5.R4): with "
-                       "the arithmetic removed the same loads, LDS exchange and stores take 24.5 us per pass (the working set is served by the "
-                       "Infinity Cache) against 59; the time follows the instruction count linearly.  A two-pass plan (three-step passes of radix "
-                       "4096, csrc/ntt_big.cuh) was built and measured in round 5: same instruction count, one 1024-lane workgroup per CU, "
-                       "229 us against 183-193 us at 2^24 (it wins at 2^21 / 2^22: -14 % / -9 %, and is the default there)",
+                       "exits, the Montgomery chain of the twiddle progression; `valu` prices them).  `valu.valu_busy_frac_at_4_clocks_per_inst`: "
+                       "the vector ALU issues in ~0.84-0.88 of the kernels' cycles; `valu.stall_breakdown` splits a WAVE's cycles into issuing / "
+                       "stalled at issue / parked on a wait or barrier (counters of this bench's own --pmc passes; four isolated transforms give "
+                       "38 / 27.5 / 34 % for a non-last pass, profiles/r05/ntt_2p24_stall_counters.json) - with three to four waves per SIMD the "
+                       "issue stalls are mostly the other waves' instructions, the LDS part is ~1 %.  Round 4's experiments (DESIGN.md 5.R4): "
+                       "with the arithmetic removed the same loads, LDS exchange and stores take 24.5 us per pass (the working set is served by "
+                       "the Infinity Cache) against 59; the time follows the instruction count linearly.  A two-pass plan (three-step passes of "
+                       "radix 4096, csrc/ntt_big.cuh) was built and measured in round 5: same instruction count, one 1024-lane workgroup per CU, "
+                       "229-236 us against 183-193 us at 2^24 (it wins at 2^21 / 2^22: -13 % / -9 %, and is the default there)",
             "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
                 kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,

@@ -70,6 +70,15 @@ enum {                                   /* crypto/src/hash/... */
 int wf_version(void);
 const char *wf_strerror(int status);
 int wf_device_count(int *h_count);
+/* Environment variables, each read ONCE when a context is created (results never depend on them; they select between kernels that
+ * compute the same words and exist for A/B measurements, tools/time_two_pass.py):
+ *   WF_NTT_BIG=0|1           two-pass f64 NTT plans (three-step passes of radix 2^10 .. 2^12, csrc/ntt_big.cuh): never | for every
+ *                            eligible transform of 2^20 .. 2^24 points; unset = where measured faster (single 2^21 / 2^22-point
+ *                            transforms, batches of >= 8 vectors of 2^20 points)
+ *   WF_ROWS_HASH_WIDE=0      rows of 9 .. 32 f64 columns are hashed by the separate row-hash kernel, not by the last NTT pass
+ *   WF_NTT_COSET_ORDER=0     the first pass of a coset LDE walks its tiles vector by vector (no L2 sharing of the source tile)
+ *   WF_NTT_PLAN=L:r1,r2,..   pass radices for transforms of 2^L points (measurements)
+ *   WF_DEBUG_GUARD=1|2       guard pages / red zones around every device block (tests/README_guard.md) */
 int wf_ctx_create(int device_id, wf_ctx **out);
 /* The same on a stream the caller owns from the start (a host that always runs on its framework's stream: no private stream is
  * created only to be destroyed by the first wf_ctx_set_stream). */
