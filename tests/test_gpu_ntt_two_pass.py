@@ -240,3 +240,25 @@ def test_full_size_wide_rows_hash_properties(oracle):
     finally:
         other.sync()
         other.close()
+
+
+@pytest.mark.parametrize("c,D,log_n,blowup", [(6, 2, 13, 8), (5, 3, 14, 4), (16, 2, 12, 8)])
+def test_wide_rows_hash_with_extension_columns_vs_oracle(oracle, c, D, log_n, blowup):
+    """an auxiliary-segment shaped matrix (columns over the quadratic / cubic extension: 12, 15 and 32 base columns per row) through
+    the rows + leaves last pass: polys, every LDE word, leaves and nodes against the oracle"""
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    n = 1 << log_n
+    cols = oracle.f64_from_int(rand_field(c * 100 + D, n * c * D)).reshape(c, n * D)
+    ctx.prof_enable(True)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(cols, ext_degree=D), prover.StarkDomain(n, blowup))
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(0, cols, blowup, fields.new(7), D=D, par=True)
+    assert np.array_equal(polys.to_host(), o_polys), "polys"
+    assert np.array_equal(lde.to_host(), o_lde), "lde"
+    assert np.array_equal(tree.leaves, o_leaves), "leaves"
+    assert np.array_equal(tree.nodes, o_nodes), "nodes"
+    assert "ntt_pass_last_rows_hash" in prof and "hash_rows_blake3" not in prof, prof
