@@ -152,6 +152,8 @@ SHAPES = [
     (32, 18, 8),      # rows of 32 columns
     (20, 19, 4),      # padded row of 24 columns in a 32-column tile (radix-64 last pass), three-pass plan
     (16, 18, 8),      # rows of exactly sixteen columns
+    (12, 15, 4),      # plan 8, 7: the radix-128 last pass (two 8-point DFTs per lane) with rows + leaves
+    (32, 15, 2),      # the same with full 32-column rows
 ]
 
 
