@@ -278,3 +278,60 @@ def test_multi_value_assertions_follow_the_reference_definition(oracle, fname):
     nok = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack(sum(cc_t, [])),
                                          [(c, f, s, fld.pack([new(v % M) for v in vals])) for c, f, s, vals in bad], fld.pack(sum(cc_v, [])))
     assert np.asarray(fld.interpolate_poly_with_offset(nok, offset, D)).reshape(ce, D * W)[n:].any()
+
+
+def test_boundary_constraint_groups_of_the_reference_fixture(oracle):
+    """The reference's own boundary-constraint fixture (air/src/air/tests.rs:64-188, `get_boundary_constraints`): eight assertions on a
+    two-column trace of length 16 — three single, two sequences of four values, a sequence of two, a sequence of two with an offset, one
+    periodic — and what the reference ASSERTS about them: five groups with the divisors x - 1, x - g^9, x^4 - g^8, x^2 - 1, x^2 - g^6, the
+    constraints of every group with their value polynomials (`build_sequence_poly`, tests.rs:303-309) and polynomial offsets (k, g^-k),
+    and the order in which the composition coefficients are handed out (the assertions sorted by stride, first step, column:
+    tests.rs:88-100).  The expected evaluations below are computed from THAT structure, written out as the reference states it — not from
+    the restated grouping logic — and must equal the restated evaluator's output at every point of the constraint-evaluation domain
+    (transition coefficients zero).  f64, as in the reference's test."""
+    fld, offset, new = _setup(oracle, "f64")
+    W, M, n, lde_blowup, ce_blowup, D = fld.W, fld.M, 16, 8, 2, 1
+    canon = lambda v: int(oracle.f64_as_int(v))
+    rng = np.random.default_rng(1664)
+    trace = fld.pack([new(int(v)) for v in rng.integers(0, 2**62, 2 * n)]).reshape(2, n * W)       # any trace: the assertions need not hold
+    polys, lde, _, _ = fld.build_trace_commitment(0, trace, lde_blowup, offset)
+    values = [1, 2, 3, 4]
+    # the assertions in the reference's order (tests.rs:72-81): (column, first_step, stride, values); stride 0 = Assertion::single
+    A = [(0, 0, 0, [3]), (0, 9, 0, [5]), (1, 9, 0, [9]), (0, 2, 4, values), (1, 2, 4, values), (1, 0, 8, values[:2]), (0, 3, 8, values[:2]), (1, 3, 8, [7])]
+    cc_words = [c[0] for c in _rand_e(fld, len(A), D, 77)]           # internal words; the k-th coefficient goes to the k-th assertion of the sorted list
+    cc = [canon(c) for c in cc_words]
+    wire = [(c, f, s, fld.pack([new(v) for v in vals])) for c, f, s, vals in A]
+    out = fld.evaluate_constraints_multi(fld.AIR_FIB_SMALL, lde, lde.shape[1] // W, n, lde_blowup, ce_blowup, offset, D, fld.pack([0, 0]), wire,
+                                         fld.pack(cc_words))
+    out = [canon(v) for v in fld.unpack(out)]
+    g = canon(fld.root_of_unity(4))                                  # trace domain generator (tests.rs:87)
+    ginv = pow(g, M - 2, M)
+
+    def seq_poly(vals):                                              # build_sequence_poly: interpolate over the subgroup of len(vals) points
+        k = len(vals)
+        return _value_poly(vals, M, pow(g, n // k, M))
+
+    no_off = (0, 1)
+    # (divisor (k, g^e) meaning x^k - g^e, [(column, value polynomial, poly_offset (k, g^-k), coefficient)]) exactly as asserted in
+    # tests.rs:112-188 (cc labels 0, 1, 2, 6, 7, 3, 4, 5 there = positions 0 .. 7 of the sorted assertion list here)
+    groups = [
+        ((1, pow(g, 0, M)), [(0, [3], no_off, cc[0])]),
+        ((1, pow(g, 9, M)), [(0, [5], no_off, cc[1]), (1, [9], no_off, cc[2])]),
+        ((4, pow(g, 4 * 2, M)), [(0, seq_poly(values), (2, pow(ginv, 2, M)), cc[3]), (1, seq_poly(values), (2, pow(ginv, 2, M)), cc[4])]),
+        ((2, pow(g, 0, M)), [(1, seq_poly(values[:2]), no_off, cc[5])]),
+        ((2, pow(g, 2 * 3, M)), [(0, seq_poly(values[:2]), (3, pow(ginv, 3, M)), cc[6]), (1, [7], no_off, cc[7])]),
+    ]
+    ce = n * ce_blowup
+    g_ce, off = canon(fld.root_of_unity(5)), canon(offset)
+    for i in range(ce):
+        x = off * pow(g_ce, i, M) % M
+        row = [canon(v) for v in fld.unpack(lde[i * (lde_blowup // ce_blowup)][:2 * W])]
+        want = 0
+        for (k, ge), constraints in groups:
+            num = 0
+            for col, poly, (ok, omul), coeff in constraints:
+                y = x * omul % M if ok else x                        # BoundaryConstraint::evaluate_at (boundary/constraint.rs:131-144)
+                b = sum(cf * pow(y, m, M) for m, cf in enumerate(poly)) % M
+                num = (num + coeff * (row[col] - b)) % M
+            want = (want + num * pow((pow(x, k, M) - ge) % M, M - 2, M)) % M
+        assert out[i] == want, i
