@@ -22,6 +22,12 @@ def test_partition_options(oracle):
     for parts, rate, D, cols in ((1, 8, 1, 10), (4, 8, 1, 64), (4, 8, 1, 10), (4, 8, 2, 10), (16, 4, 3, 255), (8, 8, 1, 64)):
         po = PartitionOptions(parts, rate)
         assert po.partition_size(cols, D) == oracle.partition_size(parts, rate, D, cols)
+    # the reference's own vectors (air/src/options.rs:555-586, `correct_partition_sizes`): (partitions, hash rate, extension degree,
+    # columns) -> (partition_size, num_partitions), for the host mirror and for the oracle's restatement
+    for parts, rate, D, cols, size, num in ((4, 8, 1, 7, 8, 1), (4, 8, 1, 70, 18, 4), (2, 8, 3, 7, 4, 2), (4, 8, 3, 7, 2, 4), (4, 8, 3, 3, 2, 2)):
+        po = PartitionOptions(parts, rate)
+        assert po.partition_size(cols, D) == size and po.num_partitions_for(cols, D) == num, (parts, rate, D, cols)
+        assert oracle.partition_size(parts, rate, D, cols) == size
     with pytest.raises(AssertionError):
         PartitionOptions(17, 1)          # air/src/options.rs:414
     with pytest.raises(AssertionError):

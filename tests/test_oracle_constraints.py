@@ -335,3 +335,16 @@ def test_boundary_constraint_groups_of_the_reference_fixture(oracle):
                 num = (num + coeff * (row[col] - b)) % M
             want = (want + num * pow((pow(x, k, M) - ge) % M, M - 2, M)) % M
         assert out[i] == want, i
+
+
+def test_composition_poly_columns_follow_the_reference_segment_fixture(oracle):
+    """prover/src/constraints/composition_poly.rs:153-166 (`segment`): sixteen coefficients 0 .. 15 in four columns of four are the four
+    CONTIGUOUS runs [0..3], [4..7], [8..11], [12..15].  The restated prover cuts the interpolated composition polynomial the same way
+    (oracle/prover.py: `coeffs[:ncols * n * ew].reshape(ncols, n * ew)`); checked here on the reference's fixture through the same
+    expression, over f128 as in the reference's test."""
+    fld = oracle.f128
+    n, ncols, ew = 4, 4, fld.W
+    coeffs = fld.pack(list(range(16)))
+    cpoly = coeffs[:ncols * n * ew].reshape(ncols, n * ew)
+    expected = [[0, 1, 2, 3], [4, 5, 6, 7], [8, 9, 10, 11], [12, 13, 14, 15]]
+    assert [[int(v) for v in fld.unpack(cpoly[k])] for k in range(ncols)] == expected
