@@ -254,3 +254,14 @@ def test_f128_table_product_on_the_host(tmp_path):
     out = subprocess.run([exe, "200000"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "mul and mul_tab ok" in out.stdout
+
+
+def test_transcript_encodings_on_the_reference_vectors():
+    """The host mirror's TraceInfo::to_elements and ProofOptions::to_elements (winterfell_amd/prover/channel.py) on the reference's own
+    test vectors: air/src/air/trace_info.rs:345-389 (main width 20, 64 rows; one auxiliary segment of width 9, 12 random elements, four
+    metadata bytes) and air/src/options.rs:521-552 (no extension, folding 8, remainder degree 127, grinding 20, blowup 8, 30 queries)."""
+    from winterfell_amd.prover.channel import ProofOptions, proof_options_to_elements, trace_info_to_elements
+    assert trace_info_to_elements(20, 64, 8) == [int.from_bytes(bytes([0, 20, 0, 0]), "little"), 64]
+    assert trace_info_to_elements(20, 64, 8, aux_width=9, num_aux_rands=12, meta=bytes([1, 2, 3, 4])) == \
+        [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 64, int.from_bytes(bytes([1, 2, 3, 4, 0, 0, 0, 0]), "little")]
+    assert proof_options_to_elements(ProofOptions(30, 8, 20, 1, 8, 127)) == [int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]

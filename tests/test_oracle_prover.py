@@ -15,6 +15,12 @@ def test_context_and_options_encoding(oracle):
     assert op.trace_info_to_elements(4, 1 << 20, 16) == [4 << 8, 1 << 20]                          # no aux segment, no metadata
     assert op.trace_info_to_elements(3, 64, 8, aux_width=2, num_aux_rands=5) == [(((3 << 8 | 1) << 8 | 2) << 8) | 5, 64]
     assert op.trace_info_to_elements(1, 8, 8, meta=bytes(range(1, 10))) == [1 << 8, 8, int.from_bytes(bytes(range(1, 8)), "little"), 8 | 9 << 8]
+    # the reference's own vectors: TraceInfo::to_elements (air/src/air/trace_info.rs:345-389: main width 20, 64 rows; then one auxiliary
+    # segment of width 9 with 12 random elements and four bytes of metadata) and ProofOptions::to_elements (air/src/options.rs:521-552)
+    assert op.trace_info_to_elements(20, 64, 8) == [int.from_bytes(bytes([0, 20, 0, 0]), "little"), 64]
+    assert op.trace_info_to_elements(20, 64, 8, aux_width=9, num_aux_rands=12, meta=bytes([1, 2, 3, 4])) == \
+        [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 64, int.from_bytes(bytes([1, 2, 3, 4, 0, 0, 0, 0]), "little")]
+    assert op.Options(30, 8, 20, 1, 8, 127).to_elements() == [int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]     # FieldExtension::None = 1
     m64 = 2**64 - 2**32 + 1
     # fib_small at 2^16 rows: 3 assertions + 2 transition constraints; modulus bytes 01 00 00 00 | ff ff ff ff
     assert op.context_to_elements(m64, 8, 2, 1 << 16, 5, op.Options(28, 8, 16, 1, 8, 127)) == \
