@@ -265,3 +265,16 @@ def test_transcript_encodings_on_the_reference_vectors():
     assert trace_info_to_elements(20, 64, 8, aux_width=9, num_aux_rands=12, meta=bytes([1, 2, 3, 4])) == \
         [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 64, int.from_bytes(bytes([1, 2, 3, 4, 0, 0, 0, 0]), "little")]
     assert proof_options_to_elements(ProofOptions(30, 8, 20, 1, 8, 127)) == [int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]
+
+    # Context::to_elements (air/src/proof/context.rs:197-255) through the mirror's entry point, with a stand-in for the AIR's shape
+    from winterfell_amd.math import fields
+    from winterfell_amd.prover.channel import context_to_elements
+
+    class Shape:
+        FIELD, TRACE_WIDTH, AUX_TRACE_WIDTH, NUM_AUX_RANDS = fields.f64, 20, 9, 12
+        trace_length = staticmethod(lambda: 4096)
+        num_assertions = staticmethod(lambda: 100)
+        num_transition_constraints = staticmethod(lambda: 28)
+
+    assert context_to_elements(Shape, ProofOptions(30, 8, 20, 1, 8, 127)) == \
+        [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 4096, 1, 0xFFFFFFFF, 128, int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]

@@ -22,6 +22,10 @@ def test_context_and_options_encoding(oracle):
         [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 64, int.from_bytes(bytes([1, 2, 3, 4, 0, 0, 0, 0]), "little")]
     assert op.Options(30, 8, 20, 1, 8, 127).to_elements() == [int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]     # FieldExtension::None = 1
     m64 = 2**64 - 2**32 + 1
+    # Context::to_elements, the reference's vector (air/src/proof/context.rs:197-255): main width 20, auxiliary width 9 with 12 random
+    # elements, 4096 rows, 128 constraints, the options above
+    assert op.context_to_elements(m64, 8, 20, 4096, 128, op.Options(30, 8, 20, 1, 8, 127), aux_width=9, num_aux_rands=12) == \
+        [int.from_bytes(bytes([12, 9, 1, 20]), "little"), 4096, 1, 0xFFFFFFFF, 128, int.from_bytes(bytes([8, 127, 8, 1]), "little"), 20, 30]
     # fib_small at 2^16 rows: 3 assertions + 2 transition constraints; modulus bytes 01 00 00 00 | ff ff ff ff
     assert op.context_to_elements(m64, 8, 2, 1 << 16, 5, op.Options(28, 8, 16, 1, 8, 127)) == \
         [2 << 8, 1 << 16, 1, 0xFFFFFFFF, 5, (1 << 24) | (8 << 16) | (127 << 8) | 8, 16, 28]
