@@ -352,7 +352,9 @@ int wf_evaluate_constraints_assertions(wf_ctx *ctx, int air, int field, uint32_t
  * (ProverChannel::get_constraint_composition_coeffs, prover/src/channel.rs:126-138; air/src/air/mod.rs:529-560): d_cc_transition =
  * num_transition_constraints elements, d_cc_boundary = one element per assertion, assertion k of the h_assert_* arrays taking
  * coefficient k.  h_assert_strides / h_assert_num_values may both be NULL (every assertion single-valued).  The small tables of the
- * call are uploaded through page-locked slots of the context: nothing waits for the stream. */
+ * call are uploaded through page-locked slots of the context: nothing waits for the stream.  What can still wait: the first call of a
+ * shape (table construction, scratch growth, a pool block of a size the context has not cached yet — hipMalloc), and a sequence
+ * assertion whose values exceed one 64 KiB stage slot (bounce-buffer copy). */
 int wf_evaluate_constraints_dev(wf_ctx *ctx, int air, int field, uint32_t ext_degree, const void *d_trace_lde, uint64_t row_width,
                                 uint32_t log_n, uint32_t log_lde_blowup, uint32_t log_ce_blowup, const void *h_domain_offset,
                                 const void *d_cc_transition, uint32_t num_assertions, const uint32_t *h_assert_columns,

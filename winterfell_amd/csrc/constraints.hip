@@ -550,7 +550,9 @@ static int evaluate(wf_ctx *ctx, const void *d_lde, uint64_t row_width, uint32_t
                 void *d_poly;
                 WF_TRY(wf_malloc(ctx, nvals * sizeof(T), &d_poly));
                 pool.v.push_back(d_poly);
-                WF_TRY(wf_copy_h2d(ctx, d_poly, vals.data(), nvals * sizeof(T)));
+                // through a page-locked stage slot of the context (copied there before the call returns): no wait for the stream unless
+                // the values exceed a slot (64 KiB), in which case the bounce-buffer copy synchronises
+                WF_TRY(wf_copy_h2d_small_async(ctx, d_poly, vals.data(), nvals * sizeof(T)));
                 WF_TRY(wf_fft_interpolate_poly(ctx, HF::Dev::ID, 1, d_poly, lk, 1));
                 // b(x g^(-first_step)) for x = offset g_ce^i: the evaluations of the polynomial over the coset offset g^(-first_step) <g_ce>
                 const T shifted = HF::to_internal(HF::mulmod(off, HF::powmod(g_inv, h_steps[k])));
