@@ -6,7 +6,8 @@ A "step" = one fft::evaluate_poly followed by one fft::interpolate_poly of a 2^2
 and out, in place) => 2 * 2^24 element-transforms per step.  value = element-transforms per second, whole job.
 With N GPUs every rank transforms its own vector (independent columns shard with no collective): weak scaling.
 
-Extra fields on the same JSON line:
+The ONE stdout line is compact (compact_line, < 6 KB); the full detail goes to --detail (default gpurun_out/bench_detail_n<N>.json).
+Fields of the detail object (the line carries the scalar part of each):
   roofline      HBM roofline of the NTT kernels (algorithmic bytes 2*n*8 per transform / measured kernel time)
   cpu_baseline  the CPU oracle's restatement of the reference's `concurrent` (Rayon) algorithm, timed on this host
   extra         trace-LDE+commit ms (the second half of BASELINE's metric) at 2^20 rows x 4 cols, blowup 8
@@ -27,6 +28,80 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # issue rates of the two VALU instruction classes of this chip, cycles per wave-instruction on one SIMD (tools/microbench_isa.hip,
 # profiles/r02/microbench_isa_*.txt: 2.3-2.7 for plain 32-bit add / sub / and / xor / arithmetic shift / mov, 4.1-4.6 for the rest)
 VALU_FAST_CYCLES, VALU_SLOW_CYCLES = 2.3, 4.3
+
+
+LINE_LIMIT = 6144     # the driver keeps a bounded tail of stdout: the ONE JSON line it parses stays well under it (round 5: 20 KB -> parsed null)
+EXTRA_KEYS = (        # the scalars of `extra` that go on the line, in this order, at most ten (the rest: --detail file)
+    "lde_commit_ms_2^20x4_b8_f64_blake3", "lde_commit_ms_2^22x32_b8_f64_blake3", "lde_commit_ms_2^24x4_b8_f64_blake3",
+    "lde_commit_ms_2^22x64_b8_f128_blake3_p8", "lde_commit_ms_2^19x96_b8_f64_blake3", "lde_commit_ms_2^20x4_b8_f64_rp64",
+    "merkle_blake3_leaves_per_s_2^23", "fri_build_layers_ms_2^24_quad_fold4_blake3",
+    "rescue_2^20_f128_quad_b8_commit+constraints+composition+deep_ms", "rp64_permutations_per_s")
+EXTRA_PREFIXES_N = (  # N > 1: the sharded legs first (their keys carry N, so they are matched by prefix)
+    "config3_sharded_commit_", "config4_sharded_fri_", "sharded_lde_commit_ms_", "merkle_blake3_leaves_per_s_2^23_all_ranks",
+    "strided_lde_commit_ms_", "sharded_fri_build_layers_ms_", "partitioned_fri_build_layers_ms_", "comm_abi_error")
+
+
+def _scalar(v):
+    return v is None or isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 200)
+
+
+def compact_line(out, detail=None, limit=LINE_LIMIT):
+    """The ONE stdout line: the contract's fields, a scalar-only `roofline` and `cpu_baseline`, at most ten scalars of `extra`, the
+    fraction of every other roofline case, and where the full detail (every case's kernels, counters, per-thread CPU tables) went.
+    Everything on it is copied from `out`; nothing is recomputed.  Raises if the result would not fit `limit` bytes."""
+    top = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "ms_per_step_cold", "cold_steps", "spinup_s",
+           "spinup_converged", "higher_is_better", "INVALID", "scaling", "vs_baseline", "dtype", "data", "config", "dry_run", "backend")
+    line = {k: out[k] for k in top if k in out}
+    rf = out.get("roofline")
+    if rf:
+        keep = ("bound", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_transform", "transform_us", "kernel",
+                "sclk_mhz_under_load", "reps")
+        line["roofline"] = {k: rf[k] for k in keep if k in rf and _scalar(rf[k])}
+        v = rf.get("valu") or {}
+        for k in ("insts_per_element_per_transform", "valu_busy_frac_at_4_clocks_per_inst", "issue_us_if_every_inst_were_fast",
+                  "issue_us_if_every_inst_were_slow"):
+            if _scalar(v.get(k)) and v.get(k) is not None:
+                line["roofline"]["valu_" + k] = v[k]
+        line["roofline"]["limiter"] = "VALU issue, not HBM (DESIGN.md section 5)"
+    rls = out.get("rooflines")
+    if rls:      # one number per further case: frac of the HBM roofline from the summed kernel durations (detail file: everything else)
+        line["roofline_frac_by_case"] = {k: round(v["frac"], 4) for k, v in rls.items() if isinstance(v, dict) and isinstance(v.get("frac"), float)}
+    ex = out.get("extra")
+    if ex:
+        picked = {}
+        if out.get("n_gpus", 1) > 1:
+            for pre in EXTRA_PREFIXES_N:
+                for k in ex:
+                    if k.startswith(pre) and (k.endswith("_ms") or "_ms_" in k or "per_s" in k or k == "comm_abi_error") and len(picked) < 10 and _scalar(ex[k]):
+                        picked.setdefault(k, ex[k])
+        for k in EXTRA_KEYS:
+            if k in ex and len(picked) < 10 and _scalar(ex[k]):
+                picked.setdefault(k, ex[k])
+        line["extra"] = picked
+    cb = out.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_hardware_threads") if k in cb}
+        line["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:400]
+    if detail:
+        line["detail"] = detail
+    s = json.dumps(line)
+    if len(s) >= limit:
+        raise ValueError("bench line is %d bytes, limit %d" % (len(s), limit))
+    return s
+
+
+def write_detail(out, path):
+    """Everything measured, as one JSON object, to `path` (relative to the repository root unless absolute).  Returns the path as
+    given, or None when the directory cannot be written (the line is then all there is: never a reason to fail the bench)."""
+    try:
+        full = path if os.path.isabs(path) else os.path.join(ROOT, path)
+        os.makedirs(os.path.dirname(full), exist_ok=True)
+        with open(full, "w") as f:
+            json.dump(out, f, indent=1)
+            f.write("\n")
+        return path
+    except OSError:
+        return None
 
 
 def fail(msg, code=2):
@@ -255,6 +330,9 @@ def main():
                     help="seconds of untimed steps before --warmup, until the step time is steady (0 = none); reported as spinup_s")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true")
+    ap.add_argument("--detail", default=None,
+                    help="file for the full detail (every roofline case, kernels, counters, per-thread CPU tables); "
+                         "default gpurun_out/bench_detail_n<N>.json; '-' = none")
     ap.add_argument("--dry-run", action="store_true",
                     help="control flow only (launcher, rendezvous, barrier, max-over-ranks reduction): no GPU work, no metric")
     args = ap.parse_args()
@@ -300,8 +378,8 @@ def main():
             assert float(t.item()) >= elapsed
             dist.destroy_process_group()
         if rank == 0:
-            print(json.dumps({"metric": "f64 NTT elements/s", "value": None, "unit": "elements/s", "n_gpus": world, "dry_run": True,
-                              "backend": backend if world > 1 else None}))
+            print(compact_line({"metric": "f64 NTT elements/s", "value": None, "unit": "elements/s", "n_gpus": world, "dry_run": True,
+                                "backend": backend if world > 1 else None}))
         return
     torch.cuda.set_device(device_index)
     local_rank = device_index
@@ -594,8 +672,8 @@ def main():
                        "the Infinity Cache) against 59; the time follows the instruction count linearly.  A two-pass plan (three-step passes of "
                        "radix 4096, csrc/ntt_big.cuh) was built and measured in round 5: same instruction count, one 1024-lane workgroup per CU, "
                        "229-236 us against 183-193 us at 2^24 (it wins at 2^21 / 2^22: -13 % / -9 %, and is the default there)",
-            "kernel": "ntt_pass (x%d) + ntt_pass_last per 2^%d transform; durations summed" % (
-                kern.get("ntt_pass", {}).get("launches", 0) // reps, args.log_n),
+            "kernel": "%s per 2^%d transform; durations summed" % (
+                " + ".join("%s x%d" % (k.split("(")[0][:60], v["launches"]) for k, v in kern.items()), args.log_n),
             "algorithmic_bytes_per_transform": alg_bytes, "transform_us": fwd_us, "kernels": kern,
             "sclk_mhz_under_load": sclk_mhz, "reps": reps, "statistic": "median over reps of the summed kernel durations of one transform",
         }
@@ -920,7 +998,12 @@ def main():
                                       "BLAKE3 (the Rust crate is AVX2/AVX-512).  The reference publishes 2.5 s for the WHOLE f128 rescue proof of "
                                       "2^20 rows on 8 laptop cores (README.md:411-465); these are f64 stages on this host")
             out["cpu_baseline"] = cpu
-        print(json.dumps(out))
+        # the full detail to a file, ONE compact line (< LINE_LIMIT bytes) to stdout, last
+        dpath = args.detail if args.detail is not None else os.path.join("gpurun_out", "bench_detail_n%d.json" % world)
+        dpath = write_detail(out, dpath) if dpath != "-" else None
+        sys.stdout.flush()
+        print(compact_line(out, dpath))
+        sys.stdout.flush()
 
     if hung:
         # a thread is still inside a collective that never completed: no orderly shutdown is possible
