@@ -72,3 +72,26 @@ def test_product_never_imports_the_oracle():
                     if re.search(r"(import\s+oracle|from\s+oracle|liboracle|oracle/)", src):
                         bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_rust_ffi_block_mirrors_the_header():
+    """INTEGRATION.md section 1's `extern "C"` block against include/winterfell_hip.h: the same functions, the same argument count and
+    the same types in the same order (round 5 review: 27 prototypes of the header were missing from the block)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import gen_rust_ffi as g
+    header = {name: (ret, [t for _, t in args]) for _, fns in g.parse_header() for name, ret, args in fns}
+    block = g.parse_rust_block()
+    assert set(header) == set(_declared_symbols())                    # the generator's parser sees what the export test sees
+    assert sorted(set(header) - set(block)) == [], "in the header, not in INTEGRATION.md"
+    assert sorted(set(block) - set(header)) == [], "in INTEGRATION.md, not in the header"
+    for name in header:
+        assert len(block[name][1]) == len(header[name][1]), name
+        assert block[name] == header[name], (name, block[name], header[name])
+    # the type mapping itself, on the declarator shapes the header uses
+    assert g.rust_type("const void *") == "*const c_void" and g.rust_type("wf_ctx **") == "*mut *mut WfCtx"
+    assert g.rust_type("void *const *") == "*const *mut c_void" and g.rust_type("wf_ctx *const *") == "*const *mut WfCtx"
+    assert g.rust_type("const uint64_t *") == "*const u64" and g.rust_type("void") is None and g.rust_type("size_t") == "usize"
+    # and the text in the document is what the generator produces today
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert g.render(g.parse_header()) in text, "run: python tools/gen_rust_ffi.py --write"
