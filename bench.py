@@ -78,6 +78,11 @@ def compact_line(out, detail=None, limit=LINE_LIMIT):
             if k in ex and len(picked) < 10 and _scalar(ex[k]):
                 picked.setdefault(k, ex[k])
         line["extra"] = picked
+    pc = out.get("pcie")
+    if isinstance(pc, dict) and isinstance(pc.get("2^22x32_f64"), dict) and "pipelined_total_ms" in pc["2^22x32_f64"]:
+        q = pc["2^22x32_f64"]     # host Vec -> host TracePolyTable + root, PCIe included (never part of `value`)
+        line["pcie_2^22x32_f64"] = {k: q[k] for k in ("h2d_trace_ms", "d2h_polys_ms", "d2h_leaves_nodes_ms", "kernels_ms", "serial_total_ms_polys_only",
+                                                      "pipelined_total_ms") if k in q}
     cb = out.get("cpu_baseline")
     if cb:
         line["cpu_baseline"] = {k: cb[k] for k in ("value", "unit", "cores", "kind", "host_hardware_threads") if k in cb}
@@ -294,6 +299,26 @@ def comm_abi_legs(ctx, dist, rank, world, barrier, timeout_s=240.0, log_rows=22,
         res["_hung"] = True
     elif err:
         res["comm_abi_error"] = err[0]
+    return res
+
+
+def pcie_legs(timeout_s=240):
+    """SURVEY 8(d) "Timing definition": H2D of the trace and D2H of the polynomials (and of leaves + nodes) reported separately, never
+    inside `value` — and what Prover::new_trace_lde (prover/src/lib.rs:182-190) costs a host caller end to end, serial against
+    pipelined (wf::new_trace_lde_from_host, include/winterfell_hip.hpp).  Measured by the C++ driver tools/host_pipeline_bench.cpp over
+    page-locked host columns, in a process of its own (its three contexts share this GPU after this bench's legs have finished)."""
+    import subprocess
+    exe = os.path.join(ROOT, "tools", "host_pipeline_bench.bin")
+    if not os.path.exists(exe):
+        return {"error": "tools/host_pipeline_bench.bin not built (__graft_entry__.build())"}
+    res = {}
+    for key, argv in (("2^20x4_f64", ["0", "20", "4", "1", "5"]), ("2^22x32_f64", ["0", "22", "32", "1", "3"]),
+                      ("2^22x64_f128_p8", ["1", "22", "64", "8", "2"])):
+        try:
+            r = subprocess.run([exe] + argv, capture_output=True, text=True, timeout=timeout_s)
+            res[key] = json.loads(r.stdout.strip().splitlines()[-1]) if r.returncode == 0 else {"error": (r.stderr or r.stdout)[-200:]}
+        except Exception as e:  # noqa: BLE001 - an optional leg
+            res[key] = {"error": repr(e)[:200]}
     return res
 
 
@@ -998,6 +1023,8 @@ def main():
                                       "BLAKE3 (the Rust crate is AVX2/AVX-512).  The reference publishes 2.5 s for the WHOLE f128 rescue proof of "
                                       "2^20 rows on 8 laptop cores (README.md:411-465); these are f64 stages on this host")
             out["cpu_baseline"] = cpu
+        if not args.no_extra and world == 1:
+            out["pcie"] = pcie_legs()
         # the full detail to a file, ONE compact line (< LINE_LIMIT bytes) to stdout, last
         dpath = args.detail if args.detail is not None else os.path.join("gpurun_out", "bench_detail_n%d.json" % world)
         dpath = write_detail(out, dpath) if dpath != "-" else None

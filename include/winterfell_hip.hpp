@@ -10,6 +10,7 @@
 //   wf::ColMatrix / wf::RowMatrix      prover/src/matrix/{col_matrix.rs, row_matrix.rs}
 //   wf::MerkleTree                     crypto/src/merkle/mod.rs:91-458 (nodes in the reference's heap layout)
 //   wf::build_trace_commitment         prover/src/trace/trace_lde/default/mod.rs:245-282
+//   wf::new_trace_lde_from_host        Prover::new_trace_lde (prover/src/lib.rs:182-190) from host columns, PCIe legs overlapped with the kernels
 //   wf::FriProver                      fri/src/prover/mod.rs:100-239 (commit phase; the channel is a caller interface)
 //   wf::evaluate_constraints, wf::ood_frame, wf::deep_compose, wf::grind_query_seed  — SURVEY §8(f) N1–N3
 //
@@ -18,11 +19,13 @@
 #pragma once
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -384,6 +387,81 @@ inline TraceCommitment build_trace_commitment(Hash h, const ColMatrix &trace, ui
                                     po.hash_rate, skip_interpolate ? 1 : 0, lde.data.data(), leaves.data(), nodes.data(), nullptr),
           "wf_build_trace_commitment");
     return TraceCommitment{std::move(lde), MerkleTree(h, std::move(leaves), std::move(nodes), trace.num_rows * blowup), std::move(polys)};
+}
+
+// Prover::new_trace_lde from HOST columns to a HOST TracePolyTable (prover/src/lib.rs:182-190), pipelined over PCIe:
+//   uploader thread    column k -> HBM on its own context (= its own stream); page-locked columns go as one DMA each
+//   calling thread     as soon as a group of `group` columns has landed: wf_interpolate_columns on it; after the last group
+//                      wf_build_trace_commitment(skip_interpolate = 1): coset LDE + row hashes + tree
+//   downloader thread  the polynomials of every interpolated group -> polys_out on a third context, WHILE later groups upload
+//                      (PCIe is full duplex) and while the LDE runs (it only reads the polynomials)
+// Leaves and nodes stay in HBM: openings go through MerkleTree::prove / prove_batch (device gathers) and RowMatrix::rows
+// (wf_rows_fetch), as DefaultTraceLde::query needs (trace_lde/default/mod.rs:199-215).  The serial form — upload all, one call,
+// download polys + leaves + nodes — moves n c s (in) + n c s + 64 b n (out) around the kernels; tools/host_pipeline_bench.cpp times both.
+// `up` and `down` must be contexts of the same device as `ctx`; the three are used from three threads, one each.
+inline TraceCommitment new_trace_lde_from_host(Context &ctx, Context &up, Context &down, Hash h, Field f, const std::vector<const uint64_t *> &cols,
+                                               uint64_t num_rows, uint64_t blowup, const uint64_t *domain_offset, const std::vector<uint64_t *> &polys_out,
+                                               PartitionOptions po = {}, uint32_t ext_degree = 1, uint32_t group = 8) {
+    const uint32_t c = (uint32_t)cols.size(), log_n = log2_exact(num_rows, "rows");
+    if (c == 0 || polys_out.size() != cols.size() || group == 0) throw Error(WF_ERR_INVALID_ARG, "new_trace_lde_from_host");
+    const uint64_t stride = num_rows * ext_degree;                          // base elements per column
+    const size_t col_bytes = (size_t)stride * 8 * words(f);
+    ColMatrix polys{DeviceBuffer(ctx, (size_t)c * col_bytes), f, c, ext_degree, num_rows};
+    uint8_t *d_cols = (uint8_t *)polys.data.data();
+    std::atomic<uint32_t> uploaded{0}, interpolated{0};
+    std::atomic<int> failed{0};
+    auto wait_for = [&](std::atomic<uint32_t> &v, uint32_t want) {
+        while (v.load(std::memory_order_acquire) < want && !failed.load(std::memory_order_acquire)) std::this_thread::yield();
+        return !failed.load(std::memory_order_acquire);
+    };
+    std::thread uploader([&] {
+        for (uint32_t k = 0; k < c; k++) {
+            if (wf_memcpy_h2d(up.handle(), d_cols + (size_t)k * col_bytes, cols[k], col_bytes) != WF_OK) { failed.store(1); return; }
+            uploaded.store(k + 1, std::memory_order_release);              // wf_memcpy_h2d returns after the copy
+        }
+    });
+    std::thread downloader([&] {
+        for (uint32_t k = 0; k < c; k++) {
+            if (!wait_for(interpolated, k + 1)) return;
+            if (wf_memcpy_d2h(down.handle(), polys_out[k], d_cols + (size_t)k * col_bytes, col_bytes) != WF_OK) { failed.store(2); return; }
+        }
+    });
+    int status = WF_OK;
+    RowMatrix lde;
+    DeviceBuffer leaves, nodes;
+    try {
+        for (uint32_t g0 = 0; g0 < c && status == WF_OK; g0 += group) {
+            const uint32_t cnt = c - g0 < group ? c - g0 : group;
+            if (!wait_for(uploaded, g0 + cnt)) break;
+            status = wf_interpolate_columns(ctx.handle(), (int)f, ext_degree, d_cols + (size_t)g0 * col_bytes, cnt, stride, log_n);
+            if (status == WF_OK) status = wf_ctx_sync(ctx.handle());      // the downloader may read these columns from here on
+            if (status == WF_OK) interpolated.store(g0 + cnt, std::memory_order_release);
+        }
+        if (status == WF_OK && !failed.load()) {
+            lde.field = f;
+            lde.ext_degree = ext_degree;
+            lde.num_rows = num_rows * blowup;
+            lde.row_width = wf_row_width(c, ext_degree);
+            lde.elements_per_row = c * ext_degree;
+            lde.data = DeviceBuffer(ctx, lde.num_rows * lde.row_width * 8 * words(f));
+            leaves = DeviceBuffer(ctx, lde.num_rows * 32);
+            nodes = DeviceBuffer(ctx, lde.num_rows * 32);
+            status = wf_build_trace_commitment(ctx.handle(), (int)h, (int)f, ext_degree, d_cols, c, stride, log_n, log2_exact(blowup, "blowup factor"),
+                                               domain_offset, po.num_partitions, po.hash_rate, 1, lde.data.data(), leaves.data(), nodes.data(), nullptr);
+            if (status == WF_OK) status = wf_ctx_sync(ctx.handle());
+        }
+    } catch (...) {
+        failed.store(3);
+        uploader.join();
+        downloader.join();
+        throw;
+    }
+    if (status != WF_OK) failed.store(3);
+    uploader.join();
+    downloader.join();
+    check(status, "new_trace_lde_from_host");
+    if (failed.load()) throw Error(WF_ERR_HIP, failed.load() == 1 ? "new_trace_lde_from_host: upload" : "new_trace_lde_from_host: download");
+    return TraceCommitment{std::move(lde), MerkleTree(h, std::move(leaves), std::move(nodes), num_rows * blowup), std::move(polys)};
 }
 
 // ---- multi-device: one rank per GPU (wf_comm_*) -------------------------------------------------------------------------------

@@ -82,6 +82,28 @@ def test_device_coin_against_the_host_coin(wf, hname, fname, D):
     assert np.array_equal(seed, host.seed) and counter == host.counter
 
 
+@pytest.mark.parametrize("hname,fname,D,count", [("Rp62_248", "f62", 1, 150), ("Rp62_248", "f62", 2, 40), ("Rp64_256", "f64", 2, 150),
+                                                 ("RpJive64_256", "f64", 3, 70)])
+def test_long_draws_walk_the_counters_in_the_reference_order(wf, hname, fname, D, count):
+    """one wf_coin_draw of many elements on the Rescue family: the groups speculate over COUNTERS (windows of 64), the walker hands the
+    values that decode to the draws in order — for f62, where three of four 8-byte values are rejected (M ~ 2^62), this is the
+    reference's retry loop taken hundreds of times; the counter must end where the host coin's does"""
+    ctx, crypto, fri, fields = wf
+    hasher, f = getattr(crypto, hname), getattr(fields, fname)
+    seed_words = f.pack([f.new(v) for v in (1, 2, 3)])
+    host = crypto.DefaultRandomCoin(hasher, f, seed_words, ctx)
+    dev = host.to_device()
+    got = ctx.to_host(dev.draw(D, count)).reshape(-1)
+    want = np.concatenate([host.draw(D) for _ in range(count)])
+    assert np.array_equal(got, want)
+    seed, counter = dev.read()
+    assert counter == host.counter and np.array_equal(seed, host.seed)
+    if fname == "f62":
+        assert counter > 2 * count                       # the retries really happened
+    # a second request continues from the counter the walker left
+    assert np.array_equal(ctx.to_host(dev.draw(D, 3)).reshape(-1), np.concatenate([host.draw(D) for _ in range(3)]))
+
+
 def test_reseed_copies_the_digest_and_rejects_bad_arguments(wf):
     ctx, crypto, fri, fields = wf
     import ctypes

@@ -78,3 +78,32 @@ def test_cpp_and_python_host_layers_produce_the_same_proof(log_n, hash_id, hname
     assert cpp["pow_nonce"] == proof.pow_nonce
     assert cpp["num_unique_queries"] == len(proof.query_positions) and cpp["first_position"] == proof.query_positions[0]
     assert cpp["fri_layers"] == proof.fri_proof.num_layers() and cpp["fri_remainder_len"] == proof.fri_proof.num_remainder_elements()
+
+
+PIPE_SRC = os.path.join(ROOT, "tools", "host_pipeline_bench.cpp")
+PIPE_BIN = os.path.join(ROOT, "tools", "host_pipeline_bench.bin")
+
+
+def build_pipeline_bench():
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-pthread", "-I" + os.path.join(ROOT, "include"), PIPE_SRC, "-o", PIPE_BIN,
+                           "-L" + os.path.join(ROOT, "winterfell_amd"), "-lwinterfell_hip", "-Wl,-rpath," + os.path.join(ROOT, "winterfell_amd")])
+
+
+def test_host_pipeline_bench_compiles():
+    build_pipeline_bench()
+    assert os.path.exists(PIPE_BIN)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("field,log_n,cols,parts,pin,group", [(0, 14, 20, 1, 1, 8), (0, 12, 5, 1, 0, 2), (1, 13, 16, 4, 1, 8)])
+def test_pipelined_host_entry_equals_the_serial_one(field, log_n, cols, parts, pin, group):
+    """wf::new_trace_lde_from_host (uploads, group-wise interpolation, polynomial downloads and LDE + commit overlapped on three
+    contexts) against the serial upload -> wf_build_trace_commitment -> download sequence: the same polynomials word for word and the
+    same root, page-locked and pageable host columns, ragged last group, f64 and f128 with partitions.  (The serial call itself is held
+    against the oracle by tests/cpp/host_parity.cpp and the Python suites.)"""
+    import json
+    build_pipeline_bench()
+    out = subprocess.run([PIPE_BIN, str(field), str(log_n), str(cols), str(parts), "2", str(pin), str(group)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    res = json.loads(out.stdout.strip().splitlines()[-1])
+    assert res["same_polys_and_root"] is True and res["pipelined_total_ms"] > 0 and res["h2d_trace_ms"] > 0

@@ -1,0 +1,72 @@
+"""Word-for-word parity of wf_build_trace_commitment at the f64 shapes BASELINE's metric is quoted on (bench.py reports
+each of them with a roofline), through the DEFAULT context — the plans, tile orders and rows + leaves passes a caller gets:
+
+  2^22 rows x 32 columns   plan 8, 8, 6 + the 32-column rows + leaves last pass        (prover/benches/row_matrix.rs widths)
+  2^24 rows x  4 columns   2^24-point transforms, 8-column padded rows, rows + leaves   (the metric's upper end, c <= 32)
+  2^19 rows x 96 columns   the reference's own row_matrix bench size: rows wider than the rows + leaves pass takes
+
+Every trace polynomial, EVERY word of the LDE matrix (padding columns included), every leaf, every Merkle node and the root against the
+CPU oracle's restatement of DefaultTraceLde::new (prover/src/trace/trace_lde/default/mod.rs:245-282): the oracle extends one column
+at a time on the host cores (interpolate_poly + evaluate_poly_with_offset, math/src/fft/mod.rs:264-295,168-211) and the column is
+compared ON THE DEVICE with the strided column of the row-major matrix; the verified rows come back in chunks for the oracle's
+hash_elements (commit_to_rows, prover/src/matrix/row_matrix.rs:184-228) and the tree is rebuilt by the oracle (crypto/src/merkle)."""
+import concurrent.futures as cf
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("log_n,cols", [(22, 32), (24, 4), (19, 96)])
+def test_metric_shapes_output_for_output(oracle, log_n, cols):
+    import torch
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    b, n = 8, 1 << log_n
+    N = n * b
+    h_trace = np.random.default_rng(0x5EED0100 + cols).integers(0, fields.M, (cols, n), dtype=np.uint64)   # canonical Montgomery residues
+    trace = ctx.to_device(h_trace)
+    ctx.prof_enable(True)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace.clone(), 1, ctx), prover.StarkDomain(n, b))
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    # the paths this test exists for (a change of the plan rules shows up here, not as a silent loss of coverage)
+    if cols <= 32:
+        assert "ntt_pass_last_rows_hash" in prof and "hash_rows_blake3" not in prof, prof
+    else:
+        assert "ntt_pass_last_rows_hash" not in prof, prof
+    rw = 8 * ((cols + 7) // 8)
+    assert lde.num_rows() == N and lde.row_width == rw
+    mat = lde.data.view(N, rw)
+    offset = fields.new(7)
+    threads = os.cpu_count() or 8
+    per = 8 if threads >= 16 else max(1, threads // 2)
+    workers = max(1, min(8, threads // per))
+
+    def extend(c):
+        oracle.set_num_threads(per)
+        p = oracle.interpolate_poly(h_trace[c], par=True)
+        return c, p, oracle.evaluate_poly_with_offset(p, offset, b, par=True)
+
+    with cf.ThreadPoolExecutor(workers) as pool:
+        for c, p, ev in pool.map(extend, range(cols)):
+            assert torch.equal(polys.data[c], ctx.to_device(p)), "poly %d" % c
+            assert torch.equal(mat[:, c], ctx.to_device(ev)), "lde column %d" % c
+    oracle.set_num_threads(threads)
+    for c in range(cols, rw):                                                # RowMatrix padding columns are zero (segments.rs:96-158)
+        assert not bool(mat[:, c].any()), "padding column %d" % c
+    # leaves: the (now verified) rows, hashed by the oracle chunk by chunk; nodes: the oracle's tree over those leaves
+    h_leaves = tree.leaves
+    chunk = min(N, (1 << 29) // (rw * 8))                                    # 512 MiB of rows at a time
+    for r0 in range(0, N, chunk):
+        rows = ctx.to_host(mat[r0:r0 + chunk])
+        assert np.array_equal(h_leaves[r0:r0 + chunk], oracle.hash_rows(0, rows, cols)), "leaves from row %d" % r0
+    del rows
+    assert np.array_equal(tree.nodes, oracle.merkle_build(0, h_leaves, par=True)), "nodes"
+    assert np.array_equal(tree.root(), tree.nodes[1]) and not tree.nodes[0].any()
+    del lde, tree, polys, trace, mat
+    torch.cuda.empty_cache()

@@ -43,7 +43,7 @@ __global__ void coin_draw_kernel(CoinState *c, uint32_t count, uint64_t *out) {
             ok = coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS);
         }
         if (!ok) {
-            c->failed = 1;
+            c->failed |= 1u;
             break;
         }
     }
@@ -87,26 +87,59 @@ __device__ __forceinline__ void coop_digest(uint64_t word, int i, volatile uint6
     }
 }
 
-// sequential draws on one lane (the reference's loop, retries included): the fallback when an optimistic parallel draw met bytes
-// that do not decode (probability ~ count x 2^-32 for the 64-bit fields)
+// draw::<E>() `count` times on the groups of ONE workgroup, speculating over COUNTERS, not over draws: the groups hash the counters
+// base + 1 .. base + ng at once, then one lane walks the window in counter order and hands every value that decodes to the next open
+// draw — the reference's loop word for word (a value that does not decode costs the current draw one of its 1000 tries,
+// default.rs:185-199), whatever the rejection rate: ~2^-32 per base element for f64, ~2^-88 for f128, but ~3/4 of all 8-byte values
+// for f62 (M ~ 2^62; the reference's try_from rejects v >= M), where speculating over draws fell back to one lane nearly always.
+// EVERY thread of the workgroup calls it (it synchronises); `seed` is the coin's seed, counter0 its counter before the first draw.
+struct CoopDrawLds {
+    uint64_t cand[64][4];      // the decoded element of each group's counter
+    int ok[64];                // ... and whether it decoded
+    uint32_t done, miss, stop; // walker state: draws served, consecutive misses of the open draw, finished
+};
 template <class H, int FIELD, int D>
-__device__ __forceinline__ void coin_draw_lane(CoinState *c, const uint32_t (&seed)[8], uint64_t counter, uint32_t count, uint64_t *out) {
+__device__ __forceinline__ void coop_draw_windows(CoinState *c, const uint32_t (&seed)[8], uint64_t counter0, uint32_t count, uint64_t *out, int i, int ii,
+                                                  volatile uint64_t *grp, CoopDrawLds *w) {
+    typedef typename H::Coop C;
     constexpr int WORDS = (FIELD == WF_FIELD_F128 ? 2 : 1) * D;
-    for (uint32_t k = 0; k < count; k++) {
-        bool ok = false;
-        for (int tries = 0; tries < 1000 && !ok; tries++) {
-            uint32_t d[8], b[8];
-            counter++;
-            H::merge_with_int(seed, counter, d);
+    static_assert(WORDS <= 4, "32 digest bytes");
+    const uint32_t g = threadIdx.x / rcoop::GROUP, ng = blockDim.x / rcoop::GROUP;
+    if (threadIdx.x == 0) w->done = w->miss = w->stop = 0;
+    uint64_t base = counter0;
+    for (;;) {
+        __syncthreads();
+        if (*(volatile uint32_t *)&w->stop) break;
+        uint32_t d[8], b[8];
+        coop_digest<C>(C::merge_with_int(seed, base + 1 + g, i, ii, grp), i, grp, d);
+        if (i == 0) {
+            uint64_t e[WORDS];
             H::as_bytes(d, b);
-            ok = coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS);
+            w->ok[g] = coin_element<FIELD, D>(b, e) ? 1 : 0;
+#pragma unroll
+            for (int t = 0; t < WORDS; t++) w->cand[g][t] = e[t];
         }
-        if (!ok) {
-            c->failed |= 1u;
-            break;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t done = w->done, miss = w->miss, stop = 0;
+            for (uint32_t k = 0; k < ng && !stop; k++) {
+                if (w->ok[k]) {
+#pragma unroll
+                    for (int t = 0; t < WORDS; t++) out[(uint64_t)done * WORDS + t] = w->cand[k][t];
+                    miss = 0;
+                    if (++done == count) stop = 1;
+                } else if (++miss >= 1000) {
+                    c->failed |= 1u;                     // FailedToDrawFieldElement (bit 0; bit 1 = nonce not found)
+                    stop = 1;
+                }
+                if (stop) c->counter = base + 1 + k;     // the last counter the reference's loop would have consumed
+            }
+            w->done = done;
+            w->miss = miss;
+            w->stop = stop;
         }
+        base += ng;
     }
-    c->counter = counter;
 }
 
 #define WF_COOP_PROLOGUE                                                              \
@@ -131,55 +164,46 @@ __global__ __launch_bounds__(16) void coin_reseed_coop_kernel(CoinState *c, cons
     if (i == 0) c->counter = 0;
 }
 
-// draw::<E>() `count` times: draw k = next() with counter0 + 1 + k, every group one draw at a time, all of them at once — valid when
-// every draw decodes at its first try; if one does not, lane 0 redoes the whole request in the reference's order
+// draw::<E>() `count` times: coop_draw_windows on up to 64 groups
 template <class H, int FIELD, int D>
 __global__ __launch_bounds__(1024) void coin_draw_coop_kernel(CoinState *c, uint32_t count, uint64_t *out) {
-    constexpr int WORDS = (FIELD == WF_FIELD_F128 ? 2 : 1) * D;
     __shared__ uint64_t coop_lds[1024];
-    __shared__ int bad;
+    __shared__ CoopDrawLds win;
     WF_COOP_PROLOGUE
-    const uint32_t g = threadIdx.x / rcoop::GROUP, ng = blockDim.x / rcoop::GROUP;
     uint32_t seed[8];
 #pragma unroll
     for (int w = 0; w < 8; w++) seed[w] = c->seed[w];
     const uint64_t counter0 = c->counter;
-    if (threadIdx.x == 0) bad = 0;
+    __syncthreads();                                     // everybody has read the counter before the walker writes it
+    coop_draw_windows<H, FIELD, D>(c, seed, counter0, count, out, i, ii, grp, &win);
+}
+
+// commit_fri_layer + draw_fri_alpha: reseed on group 0, then one draw over a window of blockDim / 16 counters (one group for the
+// 64-bit and 128-bit fields; for f62, whose try decodes with probability 4^-D, 8 / 32 / 64 of them)
+template <class H, int FIELD, int D>
+__global__ __launch_bounds__(1024) void coin_reseed_draw_coop_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out, uint64_t *out) {
+    __shared__ uint64_t coop_lds[1024];
+    __shared__ uint64_t pair[8];
+    __shared__ uint32_t ns[8];
+    __shared__ CoopDrawLds win;
+    WF_COOP_PROLOGUE
+    if (threadIdx.x < 4) pair[i] = (uint64_t)c->seed[2 * i] | ((uint64_t)c->seed[2 * i + 1] << 32);
+    else if (threadIdx.x < 8) pair[i] = (uint64_t)digest[2 * (i - 4)] | ((uint64_t)digest[2 * (i - 4) + 1] << 32);
+    if (root_out && threadIdx.x < 8) root_out[i] = digest[i];
     __syncthreads();
-    for (uint32_t k = g; k < count; k += ng) {
-        uint32_t d[8], b[8];
-        coop_digest<C>(C::merge_with_int(seed, counter0 + 1 + k, i, ii, grp), i, grp, d);
-        if (i == 0) {
-            H::as_bytes(d, b);
-            if (!coin_element<FIELD, D>(b, out + (uint64_t)k * WORDS)) bad = 1;
+    if (threadIdx.x < rcoop::GROUP) {
+        uint32_t d[8];
+        coop_digest<C>(C::merge(pair, i, ii, grp), i, grp, d);
+        if (i < 8) {
+            c->seed[i] = d[i];
+            ns[i] = d[i];
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        if (bad) coin_draw_lane<H, FIELD, D>(c, seed, counter0, count, out);
-        else c->counter = counter0 + count;
-    }
-}
-
-// commit_fri_layer + draw_fri_alpha: reseed, then one draw, on one group
-template <class H, int FIELD, int D>
-__global__ __launch_bounds__(16) void coin_reseed_draw_coop_kernel(CoinState *c, const uint32_t *digest, uint32_t *root_out, uint64_t *out) {
-    __shared__ uint64_t coop_lds[16];
-    __shared__ uint64_t pair[8];
-    WF_COOP_PROLOGUE
-    if (i < 4) pair[i] = (uint64_t)c->seed[2 * i] | ((uint64_t)c->seed[2 * i + 1] << 32);
-    else if (i < 8) pair[i] = (uint64_t)digest[2 * (i - 4)] | ((uint64_t)digest[2 * (i - 4) + 1] << 32);
-    if (root_out && i < 8) root_out[i] = digest[i];
-    __syncthreads();
-    uint32_t seed[8], d[8], b[8];
-    coop_digest<C>(C::merge(pair, i, ii, grp), i, grp, seed);
-    if (i < 8) c->seed[i] = seed[i];
-    coop_digest<C>(C::merge_with_int(seed, 1, i, ii, grp), i, grp, d);
-    if (i == 0) {
-        H::as_bytes(d, b);
-        if (coin_element<FIELD, D>(b, out)) c->counter = 1;
-        else coin_draw_lane<H, FIELD, D>(c, seed, 0, 1, out);
-    }
+    uint32_t seed[8];
+#pragma unroll
+    for (int w = 0; w < 8; w++) seed[w] = ns[w];
+    coop_draw_windows<H, FIELD, D>(c, seed, 0, 1, out, i, ii, grp, &win);
 }
 
 // draw_integers: the new seed on group 0, then one value per group
@@ -232,7 +256,8 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
 #undef WF_RQ
     }
     if constexpr (H::COOP && WF_COOP_COIN != 0) {
-#define WF_RC(FIELD, DEG) hipLaunchKernelGGL((coin_reseed_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16), 0, ctx->stream, c, dg, cp, o)
+#define WF_RC(FIELD, DEG) \
+    hipLaunchKernelGGL((coin_reseed_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(FIELD == WF_FIELD_F62 ? (DEG == 1 ? 128 : DEG == 2 ? 512 : 1024) : 16), 0, ctx->stream, c, dg, cp, o)
         if (field == WF_FIELD_F128) {
             if (D == 1) WF_RC(WF_FIELD_F128, 1);
             else WF_RC(WF_FIELD_F128, 2);
@@ -268,8 +293,9 @@ int launch_coin_reseed_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, co
 template <class H>
 int launch_coin_draw(wf_ctx *ctx, int field, uint32_t D, CoinState *c, uint32_t count, uint64_t *o) {
     if constexpr (H::COOP && WF_COOP_COIN != 0) {
-        // as many 16-lane groups as draws, up to the 64 of one 1024-lane workgroup
-        const uint32_t groups = count < 64 ? count : 64;
+        // as many 16-lane groups as counters the request is expected to consume (f62: 4^D per draw), up to the 64 of one workgroup
+        const uint64_t want = field == WF_FIELD_F62 ? ((uint64_t)count << (2 * D)) + 4 : count;
+        const uint32_t groups = want < 64 ? (uint32_t)want : 64;
 #define WF_DC(FIELD, DEG) hipLaunchKernelGGL((coin_draw_coop_kernel<H, FIELD, DEG>), dim3(1), dim3(16 * groups), 0, ctx->stream, c, count, o)
         if (field == WF_FIELD_F128) {
             if (D == 1) WF_DC(WF_FIELD_F128, 1);

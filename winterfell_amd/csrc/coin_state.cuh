@@ -8,7 +8,8 @@ namespace {
 struct CoinState {
     uint32_t seed[8];
     uint64_t counter;
-    uint32_t failed;     // a draw ran out of its 1000 tries (default.rs:185-199: FailedToDrawFieldElement)
+    uint32_t failed;     // bit field (kernels OR their bit in): bit 0 = a draw ran out of its 1000 tries (default.rs:185-199:
+                         // FailedToDrawFieldElement), bit 1 = grinding found no nonce in the searched range (prover/src/channel.rs:169-185)
     uint32_t pad;
 };
 static_assert(sizeof(CoinState) <= WF_COIN_BYTES, "WF_COIN_BYTES");
@@ -71,7 +72,7 @@ __device__ __forceinline__ void coin_reseed_draw_lane(CoinState *c, const uint32
         H::as_bytes(d, b);
         ok = coin_element<FIELD, D>(b, out);
     }
-    if (!ok) c->failed = 1;
+    if (!ok) c->failed |= 1u;
     c->counter = counter;
 }
 
@@ -131,7 +132,7 @@ __device__ __forceinline__ void coin_reseed_draw_quad_wg(CoinState *c, const uin
         ok = ok_flag != 0;
     }
     if (q == 0) {
-        if (!ok) c->failed = 1;
+        if (!ok) c->failed |= 1u;
         c->counter = counter;
     }
 #undef ok_flag

@@ -236,17 +236,32 @@ bool host_byte_is_pinned(const void *p) {
     }
     return a.type == hipMemoryTypeHost;
 }
-// the WHOLE range [p, p + bytes) must be page-locked: the first and the last byte, and every 2 MiB in between (registrations are
-// page-granular; two separate registrations that happen to be adjacent are both valid for the copy engine).  A range that is
-// pinned only at its head goes through the bounce buffers like pageable memory.
+// the WHOLE range [p, p + bytes) must be page-locked.  Walk the registrations that cover it: hipMemGetAddressRange on the device view of a
+// page-locked host byte gives the base and size of ITS registration (hipHostRegister / hipHostMalloc), so the next byte to look at
+// is the first one behind it — two adjacent registrations are both valid for the copy engine, a hole between them is found whatever
+// its size (registrations are 4 KiB-granular; round 5 sampled every 2 MiB and could step over a hole).  When the runtime cannot name
+// the registration's extent the range is treated as pageable (bounce buffers): slower, never wrong.
 bool host_range_is_pinned(const void *p, size_t bytes) {
-    if (!host_byte_is_pinned(p)) return false;
-    if (bytes <= 1) return true;
-    const char *c = (const char *)p;
-    if (!host_byte_is_pinned(c + bytes - 1)) return false;
-    for (size_t off = (size_t)2 << 20; off < bytes - 1; off += (size_t)2 << 20)
-        if (!host_byte_is_pinned(c + off)) return false;
-    return true;
+    const char *c = (const char *)p, *end = c + (bytes ? bytes : 1);
+    for (int guard = 0; c < end && guard < 4096; guard++) {
+        hipPointerAttribute_t a{};
+        if (hipPointerGetAttributes(&a, c) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost || !a.devicePointer) return false;
+        hipDeviceptr_t base = nullptr;
+        size_t size = 0;
+        if (hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)a.devicePointer) != hipSuccess || !size) {
+            (void)hipGetLastError();
+            return false;
+        }
+        // offset of `c` inside its registration, measured in the device view (host and device views of one registration are both linear)
+        const size_t off = (size_t)((const char *)a.devicePointer - (const char *)base);
+        if (off >= size) return false;
+        c += size - off;
+    }
+    return c >= end;
 }
 
 int ensure_bounce(wf_ctx *ctx) {

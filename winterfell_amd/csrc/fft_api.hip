@@ -214,8 +214,12 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
     // Blake3_256 leaves wanted and a padded row fits the columns of a last-pass tile (f64, <= 32 columns; <= 16 when the last pass has
     // radix 256): the last pass itself stores the rows, stages them in LDS and hashes them (ntt_pass<..., RH>) — for rows wider than
     // one 8-column group this replaces the row-major store below AND the row-hash kernel's second read of the whole matrix
+#ifdef WF_NO_ROWS_HASH_PASS      // A/B builds: exactly the paths a build without the rows + leaves pass takes (wide rows: fused row-major store)
+    const bool rows_hash = false;
+#else
     const bool rows_hash = hash == WF_HASH_BLAKE3_256 && d_leaves && (row_width == 8 || ctx->rows_hash_wide) &&
                            wf_ntt_rows_mode_ok(HF::Dev::ID, log_n, log_blowup, base_cols);
+#endif
     if (!rows_hash && ((size_t)sizeof(T) << log_i) >= 64) {
         // wide rows: the last pass stores straight into the row-major matrix, >= 64 contiguous bytes per row and column
         // group, and zeroes the padding columns (NttJob::rowmajor).  Measured on 64 x 2^22 f128 columns: the separate
@@ -228,7 +232,6 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
         j.rm_log_i = log_i;
         return wf_ntt_run(ctx, j);
     }
-#ifndef WF_NO_ROWS_HASH_PASS
     if (rows_hash) {
         // narrow rows, Blake3_256 leaves wanted: the last pass itself assembles the rows in LDS, hashes them and stores rows +
         // leaves (ntt_pass<..., RH>): no coset-major buffer, no transpose launch
@@ -241,7 +244,6 @@ int evaluate_polys_over(wf_ctx *ctx, uint32_t D, const void *d_polys, uint32_t n
         *fused = 1;
         return WF_OK;
     }
-#endif
     // narrow rows (fewer than 64 bytes of real columns): scattered 8..32-byte stores cost more than they save (measured
     // 299 vs 278 us for 4 f64 columns x 2^20 rows), so the cosets go to a coset-major buffer tmp[bc][u][m] first ...
     void *tmpv;

@@ -840,10 +840,9 @@ static int launch_big_pass_t(wf_ctx *ctx, const PassParams<uint64_t> &p, bool la
     if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
     typedef void (*fn)(PassParams<uint64_t>);
     const fn k = last ? (fn)nttbig::ntt_pass3<LB, LC, LTC, true, HALF> : (fn)nttbig::ntt_pass3<LB, LC, LTC, false, HALF>;
-    static bool attr_set[2] = {false, false};       // per instantiation (function-local statics of a template)
-    if (!attr_set[last ? 1 : 0]) {
+    if (!ctx->big_lds_opt_in.count((const void *)k)) {
         WF_HIP(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-        attr_set[last ? 1 : 0] = true;
+        ctx->big_lds_opt_in.insert((const void *)k);
     }
     wf_prof_begin(ctx, last ? "ntt_pass3_last" : "ntt_pass3");
     hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(G::NT), smem, ctx->stream, p);
@@ -942,6 +941,8 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     p.rh_log_cp = rh_log_cp;
     p.rh_leaves = job.rh_leaves;
     if (rh && rh_log_cp == 5) plan_passes(L, F::MAX_LOG_RADIX, p.npass, p.log_r, true);
+    // only the radix 2^6 .. 2^8 last passes have a rows + leaves variant: a plan that ends otherwise must not silently drop the leaves
+    if (rh && (p.npass == 0 || p.log_r[p.npass - 1] < 6 || p.log_r[p.npass - 1] > 8)) return WF_ERR_INVALID_ARG;
 #ifdef WF_EXPERIMENTS
     {
         static const std::pair<uint32_t, uint32_t> stagger = [] {

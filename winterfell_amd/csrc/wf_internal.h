@@ -5,6 +5,7 @@
 #include <string.h>
 
 #include <map>
+#include <set>
 #include <mutex>
 #include <string>
 #include <tuple>
@@ -102,6 +103,9 @@ struct wf_ctx {
     // (batched transforms, where the data stream from HBM and a pass less is worth more than the instructions it costs)
     int ntt_big = -1;
     std::map<uint32_t, void *> big_tables;     // log_r -> omega_R^e, e < R (f64 Montgomery residues)
+    // kernels of this context's DEVICE that have been opted in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute is per device,
+    // a context is bound to one device and serialised by `mu`: a process-wide flag would skip the opt-in on a second GPU)
+    std::set<const void *> big_lds_opt_in;
     // WF_ROWS_HASH_WIDE=0 (read once at context creation): rows wider than one 8-column group are hashed by the separate row-hash
     // kernel instead of the last NTT pass (A/B measurements)
     bool rows_hash_wide = true;
