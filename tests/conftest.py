@@ -37,10 +37,19 @@ def golden():
         return json.load(f)
 
 
+# OpenMP team of the oracle's `par` paths in the tests.  NOT the host's thread count: the GPU boxes show 256 hardware threads but run
+# under a CPU quota, and a 256-thread team that spins at every barrier burns the quota and is throttled for the rest of each
+# scheduler period — round 6 measured ~90 ms per parallel region: a 2^18 x 32 commitment took 115 s of oracle time, a 2^12-row one 106 s,
+# ~700 s of a 1010 s suite.  (bench.py's cpu_baseline scans team sizes and reports the best; this constant is test plumbing only.)
+ORACLE_THREADS = max(1, min(16, os.cpu_count() or 1))
+os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")      # read by libgomp when the oracle library loads: idle team members sleep
+
+
 @pytest.fixture(scope="session")
 def oracle():
     import oracle as orc
     orc.build()
+    orc.set_num_threads(ORACLE_THREADS)
     return orc
 
 

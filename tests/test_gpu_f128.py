@@ -5,6 +5,8 @@ import ctypes
 import numpy as np
 import pytest
 
+from conftest import ORACLE_THREADS
+
 pytestmark = pytest.mark.gpu
 
 M128 = 2**128 - 45 * 2**40 + 1
@@ -270,7 +272,7 @@ def test_config3_full_size_output_for_output(wf, oracle):
         for c, p, ev in pool.map(extend, range(cols)):
             assert torch.equal(polys.data[c], ctx.to_device(p)), "poly %d" % c
             assert torch.equal(lde_cols[:, c, :], ctx.to_device(ev).view(N, 2)), "lde column %d" % c
-    oracle.set_num_threads(os.cpu_count() or 8)
+    oracle.set_num_threads(ORACLE_THREADS)
     # leaves: the (now verified) rows, hashed by the oracle chunk by chunk
     h_leaves = tree.leaves
     chunk = 1 << 21                                                         # 2 GiB of rows at a time

@@ -16,6 +16,8 @@ import os
 import numpy as np
 import pytest
 
+from conftest import ORACLE_THREADS
+
 pytestmark = pytest.mark.gpu
 
 
@@ -56,7 +58,7 @@ def test_metric_shapes_output_for_output(oracle, log_n, cols):
         for c, p, ev in pool.map(extend, range(cols)):
             assert torch.equal(polys.data[c], ctx.to_device(p)), "poly %d" % c
             assert torch.equal(mat[:, c], ctx.to_device(ev)), "lde column %d" % c
-    oracle.set_num_threads(threads)
+    oracle.set_num_threads(ORACLE_THREADS)
     for c in range(cols, rw):                                                # RowMatrix padding columns are zero (segments.rs:96-158)
         assert not bool(mat[:, c].any()), "padding column %d" % c
     # leaves: the (now verified) rows, hashed by the oracle chunk by chunk; nodes: the oracle's tree over those leaves
