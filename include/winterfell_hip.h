@@ -74,7 +74,9 @@ int wf_device_count(int *h_count);
  * compute the same words and exist for A/B measurements, tools/time_two_pass.py):
  *   WF_NTT_BIG=0|1           two-pass f64 NTT plans (three-step passes of radix 2^10 .. 2^12, csrc/ntt_big.cuh): never | for every
  *                            eligible transform of 2^20 .. 2^24 points; unset = where measured faster (single 2^21 / 2^22-point
- *                            transforms, batches of >= 8 vectors of 2^20 points)
+ *                            transforms, batches of >= 8 vectors of 2^20 points, batches of >= 256 vectors of 2^21 points)
+ *   WF_NTT_F64_TABLES=0|1    inter-pass twiddles of the f64 passes from one-word tables: never | wherever a table fits the cache budget;
+ *                            unset = where measured faster (batches of vectors of at most 2^19 points)
  *   WF_ROWS_HASH_WIDE=0      rows of 9 .. 32 f64 columns are hashed by the separate row-hash kernel, not by the last NTT pass
  *   WF_NTT_COSET_ORDER=0     the first pass of a coset LDE walks its tiles vector by vector (no L2 sharing of the source tile)
  *   WF_NTT_PLAN=L:r1,r2,..   pass radices for transforms of 2^L points (measurements)

@@ -10,8 +10,10 @@ Variants (each a context of its own; the environment is read once, by wf_ctx_cre
   two-pass                      WF_NTT_BIG=1              three-step passes of radix 2^10 .. 2^12 wherever eligible
   separate-row-hash             WF_ROWS_HASH_WIDE=0       rows of 9 .. 32 columns hashed by hash_rows_wide, not by the last pass
   three-pass+separate-row-hash  both
+  f64-tables                    WF_NTT_F64_TABLES=1       inter-pass twiddles from one-word tables instead of the per-lane progression
+  f64-tables+three-pass         with WF_NTT_BIG=0
 
-  python tools/plan_sweep.py [out.csv] [reps=5] [max_lde_gib=48] [quick]
+  python tools/plan_sweep.py [out.csv] [reps=5] [max_lde_gib=24] [quick]
 
 Every variant must produce the same Merkle root (checked).  Timing: wall clock around the call + sync, minimum of `reps` after one untimed
 call per variant, variants interleaved repetition by repetition (so that a clock drift hits all of them alike)."""
@@ -30,7 +32,8 @@ from winterfell_amd._lib import Context  # noqa: E402
 from winterfell_amd.math import fft  # noqa: E402
 
 VARIANTS = (("default", {}), ("three-pass", {"WF_NTT_BIG": "0"}), ("two-pass", {"WF_NTT_BIG": "1"}),
-            ("separate-row-hash", {"WF_ROWS_HASH_WIDE": "0"}), ("three-pass+separate-row-hash", {"WF_NTT_BIG": "0", "WF_ROWS_HASH_WIDE": "0"}))
+            ("separate-row-hash", {"WF_ROWS_HASH_WIDE": "0"}), ("three-pass+separate-row-hash", {"WF_NTT_BIG": "0", "WF_ROWS_HASH_WIDE": "0"}),
+            ("f64-tables", {"WF_NTT_F64_TABLES": "1"}), ("f64-tables+three-pass", {"WF_NTT_F64_TABLES": "1", "WF_NTT_BIG": "0"}))
 
 
 def make_contexts(device=0):
@@ -78,10 +81,9 @@ def lde_shapes(quick):
 def main():
     out_path = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/plan_sweep.csv"
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-    max_gib = float(sys.argv[3]) if len(sys.argv) > 3 else 48.0
+    max_gib = float(sys.argv[3]) if len(sys.argv) > 3 else 24.0
     quick = len(sys.argv) > 4 and sys.argv[4] == "quick"
     base = winterfell_amd.default_context(0)
-    ctxs = make_contexts(0)
     x = torch.from_numpy(np.random.default_rng(1).integers(0, 1 << 62, 1 << 24, dtype=np.int64)).to(base.device)
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 3.0:          # clocks up
@@ -90,6 +92,16 @@ def main():
     del x
     rows = []
     g = torch.Generator(device=base.device)
+    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
+    fcsv = open(out_path, "w", newline="")                       # written row by row: a late failure keeps what was measured
+    wcsv = csv.writer(fcsv)
+    wcsv.writerow(["workload", "log_rows", "cols_or_vectors", "blowup"] + ["ms_" + v for v, _ in VARIANTS] + ["best", "default_over_best"])
+
+    def record(row):
+        rows.append(row)
+        wcsv.writerow(row)
+        fcsv.flush()
+        print(row, flush=True)
     for L, c, b in lde_shapes(quick):
         n = 1 << L
         rw = 8 * ((c + 7) // 8)
@@ -99,6 +111,7 @@ def main():
         trace = torch.randint(0, 1 << 62, (c, n), dtype=torch.int64, device=base.device, generator=g)
         dom = prover.StarkDomain(n, b)
         roots = {}
+        ctxs = make_contexts(0)          # per shape: a context keeps its grow-only scratch (seven of them at 2^23 x 96 x 8: out of memory)
 
         def run(ctx):
             return prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(trace.clone(), 1, ctx), dom)
@@ -109,13 +122,14 @@ def main():
         ms = time_variants(ctxs, run, reps, check)
         assert len(set(roots.values())) == 1, "the plans disagree on the Merkle root at 2^%d x %d, blowup %d" % (L, c, b)
         best = min(ms, key=ms.get)
-        rows.append(["lde_commit", L, c, b] + [round(ms[v], 4) for v, _ in VARIANTS] + [best, round(ms["default"] / ms[best], 4)])
-        print(rows[-1], flush=True)
+        record(["lde_commit", L, c, b] + [round(ms[v], 4) for v, _ in VARIANTS] + [best, round(ms["default"] / ms[best], 4)])
         del trace
         for ctx in ctxs.values():
-            ctx.call("wf_ctx_trim")
+            ctx.sync()
+            ctx.close()
         torch.cuda.empty_cache()
-    nt_ctxs = {k: v for k, v in ctxs.items() if k in ("default", "three-pass", "two-pass")}
+    ctxs = make_contexts(0)
+    nt_ctxs = {k: v for k, v in ctxs.items() if k in ("default", "three-pass", "two-pass", "f64-tables", "f64-tables+three-pass")}
     for L in (range(18, 25) if not quick else (21, 23)):
         for nvec in (1, 8, 32):
             n = 1 << L
@@ -134,14 +148,9 @@ def main():
             ms = time_variants(nt_ctxs, run, reps, check)
             assert all(torch.equal(v, ref["default"]) for v in ref.values()), "the plans disagree at 2^%d x %d" % (L, nvec)
             best = min(ms, key=ms.get)
-            rows.append(["evaluate_poly", L, nvec, 1] + [round(ms.get(v, float("nan")), 4) for v, _ in VARIANTS] + [best, round(ms["default"] / ms[best], 4)])
-            print(rows[-1], flush=True)
+            record(["evaluate_poly", L, nvec, 1] + [round(ms.get(v, float("nan")), 4) for v, _ in VARIANTS] + [best, round(ms["default"] / ms[best], 4)])
             del d, ref
-    os.makedirs(os.path.dirname(os.path.abspath(out_path)), exist_ok=True)
-    with open(out_path, "w", newline="") as f:
-        w = csv.writer(f)
-        w.writerow(["workload", "log_rows", "cols_or_vectors", "blowup"] + ["ms_" + v for v, _ in VARIANTS] + ["best", "default_over_best"])
-        w.writerows(rows)
+    fcsv.close()
     worst = max(rows, key=lambda r: r[-1])
     print("worst default/best: %.3f at %s" % (worst[-1], worst[:4]))
 

@@ -74,6 +74,14 @@ namespace {
 // buffer, then every lane takes whole rows: hashes them out of LDS (leaf = Blake3_256::hash_elements(row), one compression),
 // stores the digest and the 64-byte padded row.  The coset-major round trip (write + read of the whole LDE) and the separate
 // transpose + hash launch disappear (2^20 x 4 x blowup 8: lde_transpose_hash 277 us + last pass 120 us -> one launch).
+// f64 inter-pass twiddle TABLES (TWTAB kernels, WF_NTT_F64_TABLES=1): one Montgomery word per entry and one product per element — the
+// progression's second product (cur *= stp, ~18 instructions of a pass's 114 per element) becomes an 8-byte load from a table that
+// lives in L2 (a single transform's pass of <= 2^17 twiddles) or in the Infinity Cache (shared by the >= 8 vectors of a batch, <= 2^22).
+// -DNTT_F64_TW_ROWS=1 restores round 2's four-word rows (the multiplication rides on the exit from the limb form, but 32 bytes of table
+// per element through the vector memory pipeline cost what the chain cost: 75.9 against 73.6-76.6 us per pass).
+#ifndef NTT_F64_TW_ROWS
+#define NTT_F64_TW_ROWS 0
+#endif
 template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : (F::USE_L24 ? NTT_MIN_WAVES : 1)))) void ntt_pass(PassParams<typename F::T> p) {
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
@@ -390,7 +398,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         if constexpr (!LAST) {
             o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
             o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
-            if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 ? 4 : (p.tw_pair ? F::TAB_WORDS : 1)) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
+            if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 && NTT_F64_TW_ROWS != 0 ? 4 : (p.tw_pair ? F::TAB_WORDS : 1)) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
         } else if (RM || (RH && p.rh_log_cp > 3)) {
             // LDE row u + b * m, column bc
             o_ptr = o_ptr0 = p.dst + (u2 + ((c + ncols * (uint64_t)kbase) << p.rm_log_b)) * p.rm_row_width + bc2;
@@ -532,7 +540,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #ifndef NTT_EXPERIMENT_NO_DFT
                 DB::run(v);
 #endif
-                if constexpr (TWTAB) {
+                if constexpr (TWTAB && NTT_F64_TW_ROWS != 0) {
                     // inter-pass twiddles from the L2-resident table, kept in the same four-word form: multiply, fold, store
                     set_out_base((uint32_t)ka);
 #pragma unroll
@@ -748,6 +756,10 @@ static bool rows_mode_ok(uint32_t L, uint32_t log_b, uint32_t base_cols) {
     plan_passes(L, F::MAX_LOG_RADIX, npass, log_r, log_cp == 5);
     const uint32_t r = log_r[npass - 1];
     if (r < 6 || r > 8) return false;
+    // rows of 17 .. 32 columns: only beside a radix-64 last pass (2^18 .. 2^22-point columns).  With the radix-128 last pass of 2^23-point
+    // columns (plan 8, 8, 7) the fused pass loses to the row-major store + row-hash kernel by 2 .. 4 % (round-6 sweep; round 5 had measured
+    // the same for a 7, 8, 7 plan at 2^22)
+    if (log_cp == 5 && r != 6) return false;
     const uint32_t log_tc = 8 - r / 2;
     return (L - r) + log_b + log_cp >= log_tc && log_cp <= log_tc;
 }
@@ -765,7 +777,7 @@ __global__ __launch_bounds__(256) void pass_twiddle_table_kernel(const typename 
     if (idx >> log_total) return;
     const uint32_t kp = idx >> log_s, rem = idx & ((1u << log_s) - 1);
     const typename F::T w = series_at32<F>(w_lo, w_hi, w_log_lo, (kp * rem) << log_mult);
-    if constexpr (F::USE_L24) {
+    if constexpr (F::USE_L24 && NTT_F64_TW_ROWS != 0) {
         // rows of four plain-integer words w T^k mod p (l24.cuh); the series tables hold Montgomery residues
         const uint64_t c = gl::to_int(w);
         out[4 * (uint64_t)idx + 0] = c;
@@ -804,20 +816,22 @@ static int get_pass_twiddles(wf_ctx *ctx, const SeriesTable &om, uint32_t L, uin
     // LDE pass 31.7 -> 30.0 ms — that pass also carries the coset pre-scale, two more products per element — LDE + commit 116.9 ->
     // 113.6 ms; walking the vectors fastest so that a table tile is reused 512 times in a row measured the same)
     const uint32_t lim = nvec >= 8 ? NTT_TW_TABLE_BATCH_MAX_LOG : NTT_TW_TABLE_MAX_LOG;
-    const uint32_t max_log = F::USE_L24 ? lim - 1 : lim;
+    const uint32_t max_log = (F::USE_L24 && NTT_F64_TW_ROWS != 0) ? lim - 1 : lim;
     if (NTT_TW_TABLE_MAX_LOG == 0 || log_total > max_log || (F::USE_L24 && log_b_for(r) == 0)) return WF_OK;
     // f64: 32 bytes of table per element through the vector memory pipeline cost what the 15-multiplication chain costs in issue
     // slots (passes of a 2^24 transform: 75.9 against 73.6-76.6 us): the per-lane progression is used throughout unless a build asks
     // for the tables (-DNTT_F64_TW_TABLES); f128 / f62 keep them (-7 % on their passes)
-#ifndef NTT_F64_TW_TABLES
-    if (F::USE_L24) return WF_OK;
-#endif
+    // f64 (one-word tables, see NTT_F64_TW_ROWS): measured over the round-6 sweep (profiles/r06/plan_sweep.csv, variant f64-tables): -3 .. -5 %
+    // for batches of 2^18 / 2^19-point vectors (the pass's table, <= 4 MiB, stays in the XCD's L2), nothing at 2^20 / 2^21, +4 .. +6 % at
+    // 2^22 (a 32 MiB table streams from the Infinity Cache beside the data) and for single transforms (+3 .. +6 %: the table is read once
+    // per transform, like the data).  WF_NTT_F64_TABLES=0 / 1: never / wherever the generic limits above allow.
+    if (F::USE_L24 && (ctx->f64_tw_tables == 0 || (ctx->f64_tw_tables < 0 && !(nvec >= 8 && log_total <= 19)))) return WF_OK;
     const uint32_t pair = (F::TAB_WORDS > 1 && log_total <= NTT_TW_PAIR_MAX_LOG) ? 1u : 0u;      // a function of the key
     auto key = std::make_tuple((int)F::ID, L, r, log_s, log_mult);
     auto it = ctx->pass_twiddles.find(key);
     if (it == ctx->pass_twiddles.end()) {
         void *d;
-        WF_TRY(wf_dev_malloc(ctx, &d, (sizeof(T) * (F::USE_L24 ? 4 : (pair ? F::TAB_WORDS : 1))) << log_total));
+        WF_TRY(wf_dev_malloc(ctx, &d, (sizeof(T) * ((F::USE_L24 && NTT_F64_TW_ROWS != 0) ? 4 : (pair ? F::TAB_WORDS : 1))) << log_total));
         ctx->owned.push_back(d);
         const uint32_t total = 1u << log_total;
         const T two64 = HF::to_internal(HF::mulmod(HF::from_u64(1ull << 32), HF::from_u64(1ull << 32)));
@@ -888,7 +902,9 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     if constexpr (F::USE_L24) {
         const bool plan_forced = ctx->plan_log_n == L && ctx->plan_npass;
         const uint32_t r_last = L / 2, log_tc_last = r_last == 10 ? 3 : 2;
-        const bool wins = (L == 20 && job.nvec >= 8) || ((L == 21 || L == 22) && job.nvec < 8);
+        // where the two-pass plan is the default: the rule of the round-6 sweep (tools/plan_sweep.py -> profiles/r06/plan_sweep.csv; every
+        // other (size, batch) cell is within the run-to-run noise of the three-pass plan or loses: 2^22 batches +5 .. +11 %, 2^23 / 2^24 +2 .. +30 %)
+        const bool wins = (L == 20 && job.nvec >= 8) || ((L == 21 || L == 22) && job.nvec < 8) || (L == 21 && job.nvec >= 256);
         const bool wanted = ctx->ntt_big == 1 || (ctx->ntt_big < 0 && wins);
         big = wanted && !plan_forced && L >= 20 && L <= 24 && job.rh_leaves == nullptr && (!job.rowmajor || job.rm_log_i >= log_tc_last);
         if (big) {

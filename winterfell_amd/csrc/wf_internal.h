@@ -106,6 +106,9 @@ struct wf_ctx {
     // kernels of this context's DEVICE that have been opted in to more than 64 KiB of dynamic LDS (hipFuncSetAttribute is per device,
     // a context is bound to one device and serialised by `mu`: a process-wide flag would skip the opt-in on a second GPU)
     std::set<const void *> big_lds_opt_in;
+    // WF_NTT_F64_TABLES=0|1 (unset: where measured faster): the f64 passes take their inter-pass twiddles from one-word tables (one product
+    // per element) instead of from the per-lane progression (two products per element); ntt_engine.cuh get_pass_twiddles
+    int f64_tw_tables = -1;        // -1: the rule of get_pass_twiddles (batches of <= 2^19-point vectors)
     // WF_ROWS_HASH_WIDE=0 (read once at context creation): rows wider than one 8-column group are hashed by the separate row-hash
     // kernel instead of the last NTT pass (A/B measurements)
     bool rows_hash_wide = true;
