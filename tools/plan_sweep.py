@@ -12,6 +12,7 @@ Variants (each a context of its own; the environment is read once, by wf_ctx_cre
   three-pass+separate-row-hash  both
   f64-tables                    WF_NTT_F64_TABLES=1       inter-pass twiddles from one-word tables instead of the per-lane progression
   f64-tables+three-pass         with WF_NTT_BIG=0
+  no-vector-tiles               WF_LDE_VT=0               the wide-trace LDE on position-major tiles (per-lane twiddle progressions), as before round 6
 
   python tools/plan_sweep.py [out.csv] [reps=5] [max_lde_gib=24] [quick]
 
@@ -33,7 +34,8 @@ from winterfell_amd.math import fft  # noqa: E402
 
 VARIANTS = (("default", {}), ("three-pass", {"WF_NTT_BIG": "0"}), ("two-pass", {"WF_NTT_BIG": "1"}),
             ("separate-row-hash", {"WF_ROWS_HASH_WIDE": "0"}), ("three-pass+separate-row-hash", {"WF_NTT_BIG": "0", "WF_ROWS_HASH_WIDE": "0"}),
-            ("f64-tables", {"WF_NTT_F64_TABLES": "1"}), ("f64-tables+three-pass", {"WF_NTT_F64_TABLES": "1", "WF_NTT_BIG": "0"}))
+            ("f64-tables", {"WF_NTT_F64_TABLES": "1"}), ("f64-tables+three-pass", {"WF_NTT_F64_TABLES": "1", "WF_NTT_BIG": "0"}),
+            ("no-vector-tiles", {"WF_LDE_VT": "0"}))
 
 
 def make_contexts(device=0):

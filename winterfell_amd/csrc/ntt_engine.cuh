@@ -82,8 +82,18 @@ namespace {
 #ifndef NTT_F64_TW_ROWS
 #define NTT_F64_TW_ROWS 0
 #endif
-template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false>
+// VT (vector tiles, round 6; f64, the passes of a wide trace's coset LDE): the tile's TC columns are TC VECTORS (base columns of one
+// coset) at ONE position instead of TC positions of one vector, on column-interleaved buffers ([position][column]: polynomials
+// transposed once, the ping buffer [coset][position][column]), so that every access is still a 128 / 256-byte run — and every twiddle
+// of the tile is shared by its columns: the inter-pass twiddles omega^(k' rem) are R values per tile, expanded once per workgroup
+// into four-word rows in LDS and applied by the exit from the limb form (the multiplication is free there, as in step 1), instead
+// of two Montgomery products per element for the per-lane progression; the coset pre-scale (offset g^u)^j of the first pass is R
+// values per tile as well (one look-up per lane into LDS, one product per element instead of two).  Per element of a non-last pass:
+// 114 -> ~86 VALU instructions, first pass of an LDE 150 -> ~109.  The last pass only changes its lane <-> (row, column) assignment and
+// its source address (columns are the contiguous axis of every VT buffer); its outputs — row-major rows, leaves — are as before.
+template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false, bool VT = false>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : (F::USE_L24 ? NTT_MIN_WAVES : 1)))) void ntt_pass(PassParams<typename F::T> p) {
+    static_assert(!VT || (F::USE_L24 && !PF && !TWTAB && LOG_B >= 3), "vector tiles: f64 passes of radix 64 .. 256");
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
     static_assert(!RH || (LAST && !PF && F::USE_L24 && LOG_B >= 3), "rows mode: f64 last passes of radix 64 / 128 / 256");
     static_assert(!(PF && TWTAB), "the table kernel's step-2 loads would drain the prefetch (in-order vm counter)");
@@ -121,6 +131,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     constexpr bool WLDS = F::USE_L24 && B > 1 && NTT_W256_IN_LDS != 0;
     constexpr int WROWS = WLDS ? (1 << LOG_R) : 1;
     __shared__ uint4 wlds[2 * WROWS];
+    static_assert(!VT || WLDS, "vector tiles ride on the limb passes");
+    // VT: the tile's inter-pass twiddle rows take wlds' place once step 1 is through with it, the coset pre-scale factors of a first pass
+    // sit in the exchange buffer until step 1 has read them (one more barrier each): no LDS beyond the 40 KiB of a radix-256 pass, i.e.
+    // four workgroups per CU (with arrays of their own, 50 KiB and three: measured 2^22 x 32 LDE passes 7.66 ms)
+    uint4 *const vt_rows = wlds;
+    T *const vt_ps = lds;
 
     int tid = threadIdx.x;
 #if defined(WF_EXPERIMENTS) && defined(NTT_EXTRA_LDS)      // occupancy experiment (tools/build_variant.sh): bytes of LDS a workgroup holds on top of what it needs
@@ -188,9 +204,46 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     uint32_t log_s = log_s0;
 
     int b1, t1;
-    if (!LAST) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
+    // (VT: the columns are the contiguous axis of every buffer, so the last pass deals its lanes like a non-last one)
+    if (!LAST || VT) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
+    // VT non-last pass: tile -> (position column c, column group g of TC columns, coset u); whole tiles only (checked on the host)
+    uint64_t vt_c = 0;
+    uint32_t vt_g = 0, vt_u = 0;
+    auto vt_tile = [&](uint64_t tl) {
+        const uint32_t b = 1u << p.rm_log_b, gt = p.vt_cols / TC;
+        const uint64_t full = (ncols * gt * b) / 64 * 64;
+        uint64_t pair;
+        if (p.pass == 0 && b > 1 && b <= 8 && tl < full) {
+            // the b cosets of one (c, g) source tile on ONE XCD inside a window of 64 blocks: the polynomials are fetched once (see below)
+            const uint32_t sl = (uint32_t)tl & 63u, x = sl & 7u, k = sl >> 3;
+            vt_u = k & (b - 1);
+            pair = (tl >> 6) * (64 / b) + 8 * (k / b) + x;
+        } else {
+            vt_u = (uint32_t)tl & (b - 1);
+            pair = tl >> p.rm_log_b;
+        }
+        vt_c = pair / gt;
+        vt_g = (uint32_t)(pair - vt_c * gt);
+    };
     // issue the loads of this lane's A inputs of tile `tile` (no wait); also returns what step 1 needs to know about them
     auto load_inputs = [&](uint64_t tile, T (&xin)[A], bool &active, uint64_t &v, uint64_t &base) {
+        if constexpr (VT && !LAST) {
+            // element (column bc, coset u, position j) lives at [(u n + j) C + bc]; the first pass reads the polynomials: [j C + bc]
+            vt_tile(tile);
+            const uint32_t bc = vt_g * TC + (uint32_t)t1;
+            v = ((uint64_t)bc << p.rm_log_b) + vt_u;
+            const uint64_t rem = vt_c & ((1ull << log_s) - 1);
+            base = ((vt_c >> log_s) << (log_s + LOG_R)) + rem;
+            active = true;
+            const T *ptr = p.src + ((p.pass ? ((uint64_t)vt_u << L) : 0ull) + base + ((uint64_t)b1 << log_s)) * p.vt_cols + bc;
+            const uint64_t istep = ((uint64_t)B << log_s) * p.vt_cols;
+#pragma unroll
+            for (int a = 0; a < A; a++) {
+                xin[a] = *ptr;
+                ptr += istep;
+            }
+            return;
+        }
         const uint64_t cc = tile * TC + t1;
         uint64_t c = 0;
         uint32_t bc1, u1;
@@ -208,6 +261,22 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                 base += (cr & ((1ull << p.log_r[q]) - 1)) << ls;
                 cr >>= p.log_r[q];
             }
+        }
+        if constexpr (VT) {
+            // last pass on the column-interleaved ping buffer: [(u n + position) C + bc], positions base + b1 + B a
+            if (active) {
+                const T *ptr = p.src + (((uint64_t)u1 << L) + base + (uint64_t)b1) * p.vt_cols + bc1;
+                const uint64_t istep = (uint64_t)B * p.vt_cols;
+#pragma unroll
+                for (int a = 0; a < A; a++) {
+                    xin[a] = *ptr;
+                    ptr += istep;
+                }
+            } else {
+#pragma unroll
+                for (int a = 0; a < A; a++) xin[a] = F::zero();
+            }
+            return;
         }
         uint32_t vs, vq, vr;
         divmod_uniform((uint32_t)v, p.src_div, vs, vr);
@@ -266,6 +335,22 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         for (int i = threadIdx.x; i < 2 * WROWS; i += 256) wlds[i] = rows[2 * ((i >> 1) << (8 - LOG_R)) + (i & 1)];
     }
     load_inputs(tile, x, active, v1, base1);
+    uint64_t vt_w = 0;
+    if constexpr (VT && !LAST) {
+        // the tile's R inter-pass twiddles omega_n^((k' rem) mult), one per lane, expanded to the four-word rows of the exit (l24.cuh:
+        // w T^k mod p as plain integers — what pass_twiddle_table_kernel writes for a whole pass, here for one tile), and, in the first
+        // pass of a coset LDE, its R pre-scale factors (offset g^u)^(j of row r): both shared by the tile's TC columns
+        const uint32_t r32 = (uint32_t)(vt_c & ((1ull << log_s0) - 1));
+        if (tid < (1 << LOG_R)) {
+            // (the look-up now, while the tile's loads are in flight; the expansion to a row after step 1, see vt_rows)
+            vt_w = gl::to_int(series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, ((uint32_t)tid * r32) << log_mult));
+            if (p.pre_lo != nullptr && p.pass == 0) {
+                const T *plo = p.pre_lo + vt_u * p.pre_lo_stride, *phi = p.pre_hi + vt_u * p.pre_hi_stride;
+                const uint64_t base_t = ((vt_c >> log_s0) << (log_s0 + LOG_R)) + r32;
+                vt_ps[tid] = series_at32<F>(plo, phi, p.pre_log_lo, (uint32_t)(base_t + ((uint64_t)tid << log_s0)));
+            }
+        }
+    }
     if constexpr (WLDS) __syncthreads();
     for (;;) {
     log_s = opaque(log_s0);
@@ -278,6 +363,13 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
     {
         const uint64_t v = v1, base = base1;
+        if constexpr (VT && !LAST) {
+            if (p.pre_lo != nullptr && p.pass == 0) {
+#pragma unroll
+                for (int a = 0; a < A; a++) x[a] = F::mul(x[a], vt_ps[b1 + B * a]);       // row r = b1 + B a of the tile
+                __syncthreads();       // (wave-uniform branch) every lane has its factors before step 1's outputs overwrite them
+            }
+        } else
         if (active) {
             if (p.pre_lo != nullptr && p.pass == 0) {
                 uint32_t uq, u;
@@ -349,6 +441,15 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     }
 
     if (B > 1) __syncthreads();
+    if constexpr (VT && !LAST) {
+        // step 1 is through with wlds: the tile's inter-pass twiddle rows (w T^k mod p, k = 0 .. 3, plain integers) take its place
+        if (tid < (1 << LOG_R)) {
+            const uint64_t c0 = vt_w, c1 = gl::mul_pow2<24>(c0), c2 = gl::mul_pow2<48>(c0), c3 = gl::mul_pow2<72>(c0);
+            vt_rows[2 * tid] = make_uint4((uint32_t)c0, (uint32_t)(c0 >> 32), (uint32_t)c1, (uint32_t)(c1 >> 32));
+            vt_rows[2 * tid + 1] = make_uint4((uint32_t)c2, (uint32_t)(c2 >> 32), (uint32_t)c3, (uint32_t)(c3 >> 32));
+        }
+        __syncthreads();
+    }
 
     // ---- step 2: B-point DFT(s) over the low half, inter-pass twiddle, store -----------------------
     const int t2 = (B > 1) ? tid % TC : t1;
@@ -376,10 +477,20 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         }
     }
     if (more) load_inputs(next_tile, xn, active_n, vn, basen);
-    if (cc < total_cols) {
+    if ((VT && !LAST) || cc < total_cols) {
     uint64_t v, c;
     uint32_t bc2, u2;
-    const bool real_col = decompose(cc, v, c, bc2, u2);
+    bool real_col_;
+    if constexpr (VT && !LAST) {
+        bc2 = vt_g * TC + (uint32_t)t2;
+        u2 = vt_u;
+        c = vt_c;
+        v = ((uint64_t)bc2 << p.rm_log_b) + u2;
+        real_col_ = true;
+    } else {
+        real_col_ = decompose(cc, v, c, bc2, u2);
+    }
+    const bool real_col = real_col_;
     uint32_t dq, dr;
     divmod_uniform((uint32_t)v, p.dst_inner, dq, dr);
     T *dst = p.dst + (uint64_t)dq * p.dst_vec_stride + (uint64_t)dr * p.dst_inner_stride;
@@ -395,7 +506,11 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     const T *tw0 = nullptr;                     // TWTAB: the table entry of krel = 0 for this lane's column
     uint32_t o_k32 = 0, o_kstep32 = 0;          // natural output index of krel = 0 and its step (last pass: post-scale look-ups)
     auto set_out_base = [&](uint32_t kbase) {
-        if constexpr (!LAST) {
+        if constexpr (VT && !LAST) {
+            // the column-interleaved ping buffer: [(u n + position) C + bc]
+            o_ptr = o_ptr0 = p.dst + (((uint64_t)u2 << L) + base_nl + ((uint64_t)kbase << log_s)) * p.vt_cols + bc2;
+            o_step = (int64_t)(((uint64_t)p.vt_cols) << log_s);
+        } else if constexpr (!LAST) {
             o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
             o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
             if constexpr (TWTAB) tw0 = p.tw_tab + (F::USE_L24 && NTT_F64_TW_ROWS != 0 ? 4 : (p.tw_pair ? F::TAB_WORDS : 1)) * ((((uint64_t)kbase) << log_s) + (uint32_t)rem);
@@ -540,7 +655,20 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #ifndef NTT_EXPERIMENT_NO_DFT
                 DB::run(v);
 #endif
-                if constexpr (TWTAB && NTT_F64_TW_ROWS != 0) {
+                if constexpr (VT && !LAST) {
+                    // the tile's twiddle rows (LDS, generated above): the exit from the limb form IS the inter-pass multiplication
+                    set_out_base((uint32_t)ka);
+#pragma unroll
+                    for (int ip = 0; ip < B; ip++) {
+                        const int i = brev(ip, LOG_B);           // output digit k_a + A * ip
+                        uint32_t yl[4];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) yl[q] = DB::limb(v, i, q);
+                        const uint4 wa = vt_rows[2 * (ka + A * ip)], wb = vt_rows[2 * (ka + A * ip) + 1];
+                        *out_next(ip == 0, (int64_t)A * o_step) = l24::fold_lazy(l24::mul4(yl, (T)wa.x | ((T)wa.y << 32), (T)wa.z | ((T)wa.w << 32),
+                                                                                           (T)wb.x | ((T)wb.y << 32), (T)wb.z | ((T)wb.w << 32)));
+                    }
+                } else if constexpr (TWTAB && NTT_F64_TW_ROWS != 0) {
                     // inter-pass twiddles from the L2-resident table, kept in the same four-word form: multiply, fold, store
                     set_out_base((uint32_t)ka);
 #pragma unroll
@@ -666,9 +794,14 @@ template <class F, int LA, int LB>
 constexpr bool has_rows_variant() { return F::USE_L24 && (LA == LB || LA == LB + 1) && LB >= 3; }
 
 template <class F, int LA, int LB>
-auto pick(bool last, bool twtab, bool pf, bool rh = false) -> void (*)(PassParams<typename F::T>) {
+auto pick(bool last, bool twtab, bool pf, bool rh = false, bool vt = false) -> void (*)(PassParams<typename F::T>) {
     typedef void (*fn)(PassParams<typename F::T>);
     if constexpr (has_rows_variant<F, LA, LB>()) {
+#ifndef WF_NO_VECTOR_TILES
+        if (vt && rh && last) return (fn)ntt_pass<F, LA, LB, true, false, false, true, true>;
+        if (vt && last) return (fn)ntt_pass<F, LA, LB, true, false, false, false, true>;
+        if (vt) return (fn)ntt_pass<F, LA, LB, false, false, false, false, true>;
+#endif
         if (rh && last) return (fn)ntt_pass<F, LA, LB, true, false, false, true>;
     }
     if constexpr (has_prefetch_variant<F, LA, LB>()) {
@@ -679,16 +812,16 @@ auto pick(bool last, bool twtab, bool pf, bool rh = false) -> void (*)(PassParam
 }
 
 template <class F>
-auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false) -> void (*)(PassParams<typename F::T>) {
+auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false, bool vt = false) -> void (*)(PassParams<typename F::T>) {
     switch (r) {
         case 1: return pick<F, 1, 0>(last, twtab, pf);
         case 2: return pick<F, 1, 1>(last, twtab, pf);
         case 3: return pick<F, 2, 1>(last, twtab, pf);
         case 4: return pick<F, 2, 2>(last, twtab, pf);
         case 5: return pick<F, 3, 2>(last, twtab, pf);
-        case 6: return pick<F, 3, 3>(last, twtab, pf, rh);
-        case 7: return pick<F, 4, 3>(last, twtab, pf, rh);
-        default: return pick<F, 4, 4>(last, twtab, pf, rh);
+        case 6: return pick<F, 3, 3>(last, twtab, pf, rh, vt);
+        case 7: return pick<F, 4, 3>(last, twtab, pf, rh, vt);
+        default: return pick<F, 4, 4>(last, twtab, pf, rh, vt);
     }
 }
 
@@ -756,13 +889,42 @@ static bool rows_mode_ok(uint32_t L, uint32_t log_b, uint32_t base_cols) {
     plan_passes(L, F::MAX_LOG_RADIX, npass, log_r, log_cp == 5);
     const uint32_t r = log_r[npass - 1];
     if (r < 6 || r > 8) return false;
-    // rows of 17 .. 32 columns: only beside a radix-64 last pass (2^18 .. 2^22-point columns).  With the radix-128 last pass of 2^23-point
-    // columns (plan 8, 8, 7) the fused pass loses to the row-major store + row-hash kernel by 2 .. 4 % (round-6 sweep; round 5 had measured
-    // the same for a 7, 8, 7 plan at 2^22)
-    if (log_cp == 5 && r != 6) return false;
+    // rows of 17 .. 32 columns of 2^20 points and more: only beside a radix-64 last pass (2^20 .. 2^22-point columns).  With the radix-128
+    // last pass of 2^23-point columns (plan 8, 8, 7) the fused pass loses to the row-major store + row-hash kernel by 2 .. 4 % (round-6
+    // sweep; round 5 had measured the same for a 7, 8, 7 plan at 2^22)
+    if (log_cp == 5 && r != 6 && L >= 20) return false;
     const uint32_t log_tc = 8 - r / 2;
     return (L - r) + log_b + log_cp >= log_tc && log_cp <= log_tc;
 }
+
+namespace {
+// columns -> column-interleaved: out[pos * C + bc] = column bc at position pos (column bc of a ColMatrix of extension degree D lives
+// at (bc / D) * vec_stride + (bc % D) * inner_stride, element stride es).  A workgroup moves 16 columns x 64 positions through LDS: reads
+// are 512-byte runs along a column, writes 128-byte runs along a row.  The source of every VT pass chain (ntt_pass<..., VT>).
+template <class T>
+__global__ __launch_bounds__(256) void vt_interleave_kernel(const T *src, T *out, uint32_t C, uint64_t n, uint32_t inner, uint64_t vec_stride,
+                                                            uint64_t inner_stride, uint32_t es) {
+    __shared__ T tile[16][65];
+    const uint32_t cg = blockIdx.x % (C / 16);
+    const uint64_t p0 = (uint64_t)(blockIdx.x / (C / 16)) * 64;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t idx = threadIdx.x + 256 * k, cl = idx >> 6, pl = idx & 63;
+        const uint32_t bc = cg * 16 + cl;
+        uint32_t vq, vr;
+        divmod_uniform(bc, inner, vq, vr);
+        const uint64_t pos = p0 + pl;
+        tile[cl][pl] = pos < n ? src[(uint64_t)vq * vec_stride + (uint64_t)vr * inner_stride + pos * es] : T(0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t idx = threadIdx.x + 256 * k, pl = idx >> 4, cl = idx & 15;
+        const uint64_t pos = p0 + pl;
+        if (pos < n) out[pos * C + cg * 16 + cl] = tile[cl][pl];
+    }
+}
+}  // namespace
 
 #ifndef NTT_TW_TABLE_MAX_LOG
 #define NTT_TW_TABLE_MAX_LOG 17   // largest inter-pass twiddle table kept (entries): 1 MiB of f64, L2 resident
@@ -898,6 +1060,25 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     // eight columns = 64-byte segments: -8 %); the radix-2048 tiles of four columns (32-byte segments) lose on batches that stream
     // from HBM (+14 % at 2^22 x 288), the radix-4096 pass (one 1024-lane workgroup per CU) loses everywhere (2^24: 229 against
     // 193 us).  WF_NTT_BIG=1 forces the plan for every eligible transform, 0 switches it off.
+    // vector tiles (see below) for this job with the plan in p?  Measured (tools/time_vt.py, profiles/r06/vector_tiles_ab.txt): the LDE
+    // passes of 2^22 x 32 columns, blowup 8, 8.37 -> 7.36 ms (the call 17.37 -> 16.66 ms), 2^19 x 96 3.12 -> 2.68 ms; what they cannot beat
+    // is the two-pass plan where that is the default (2^20 x 64: 7.70 against 8.02 ms), and with a blowup of 2 the interleaving of the
+    // polynomials (one read + one write of them) costs more than the shared twiddles save (2^22 x 64, blowup 2: 11.11 against 11.69 ms)
+    auto vt_possible = [&]() -> bool {
+#ifdef WF_NO_VECTOR_TILES
+        return false;
+#else
+        if (!F::USE_L24) return false;
+        const uint32_t C = job.rm_base_cols, b = 1u << job.rm_log_b;
+        bool ok = ctx->lde_vt && !job.inverse && (job.rowmajor || job.rh_leaves != nullptr) && job.pre_lo != nullptr && job.pre_mod == b && job.src_div == b &&
+                  job.post_lo == nullptr && !job.has_post_const && C >= 16 && job.nvec == C * b && p.npass >= 2 && job.rm_log_b >= 2 && job.rm_log_b <= 6;
+        for (uint32_t q = 0; ok && q < p.npass; q++) {
+            const uint32_t r = p.log_r[q], tc = 256u >> log_b_for(r);
+            ok = r >= 6 && r <= 8 && (q + 1 == p.npass || (C % tc == 0 && ((((uint64_t)1 << (L - r)) * (C / tc)) << job.rm_log_b) < 0x7fffffffull));
+        }
+        return ok;
+#endif
+    };
     bool big = false;
     if constexpr (F::USE_L24) {
         const bool plan_forced = ctx->plan_log_n == L && ctx->plan_npass;
@@ -973,6 +1154,29 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
 #endif
 
     const uint64_t n = 1ull << L;
+    // Vector tiles (ntt_pass<..., VT>): the coset LDE of a wide f64 trace — row-major output or rows + leaves — whose column count is a
+    // multiple of every non-last pass's tile width runs on column-interleaved buffers with tile-shared twiddles.  WF_LDE_VT=0: off.
+    bool vt = false;
+    const T *vt_src = nullptr;
+    if constexpr (F::USE_L24) {
+#ifndef WF_NO_VECTOR_TILES
+        const uint32_t C = job.rm_base_cols;
+        vt = !big && vt_possible();
+        if (vt) {
+            void *il;
+            WF_TRY(wf_scratch(ctx, 1, (size_t)n * C * sizeof(T), &il));
+            const uint64_t blocks = (uint64_t)(C / 16) * ((n + 63) / 64);
+            if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            wf_prof_begin(ctx, "vt_interleave");
+            hipLaunchKernelGGL(vt_interleave_kernel<T>, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, (const T *)job.src, (T *)il, C, n,
+                               job.src_inner ? job.src_inner : 1, job.src_vec_stride, job.src_inner_stride, job.src_es);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            vt_src = (const T *)il;
+            p.vt_cols = C;
+        }
+#endif
+    }
     T *tmp = nullptr;
     if (p.npass > 1) {
         void *t;
@@ -982,6 +1186,46 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     for (uint32_t q = 0; q < p.npass; q++) {
         const bool first = q == 0, last = q + 1 == p.npass;
         p.pass = q;
+        if (vt) {
+            // every VT pass addresses its buffers itself: polynomials [position][C] -> ping buffer [coset][position][C] (in place
+            // from the second pass on) -> the last pass's row-major rows (+ leaves), as without vector tiles
+            const uint32_t r = p.log_r[q];
+            p.src = first ? vt_src : tmp;
+            p.dst = last ? (T *)job.dst : tmp;
+            p.src_div = 1;
+            p.src_inner = 1;
+            p.dst_inner = 1;
+            p.src_vec_stride = p.dst_vec_stride = 0;
+            p.src_inner_stride = p.dst_inner_stride = 1;
+            p.src_es = p.dst_es = 1;
+            p.scale_in_w256 = 0;
+            p.w256 = (const T *)w256;
+            p.tw_tab = nullptr;
+            p.tw_pair = 0;
+            p.coset_order = 0;
+            p.rowmajor = (last && job.rowmajor) ? 1 : 0;
+            const uint32_t Tc = 256u >> log_b_for(r);
+            uint64_t blocks;
+            const bool rh_pass = rh && last;
+            if (!last) {
+                blocks = ((n >> r) * (p.vt_cols / Tc)) << job.rm_log_b;
+            } else {
+                uint64_t total_cols;
+                if (rh_pass) total_cols = (n >> r) << (job.rm_log_b + rh_log_cp);
+                else {
+                    const uint64_t groups = (job.rm_base_cols + (1u << job.rm_log_i) - 1) >> job.rm_log_i;
+                    total_cols = (groups << (job.rm_log_b + job.rm_log_i)) * (n >> r);
+                }
+                blocks = (total_cols + Tc - 1) / Tc;
+            }
+            if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            auto k = kernel_for<F>(r, last, false, false, rh_pass, true);
+            wf_prof_begin(ctx, rh_pass ? "ntt_pass_last_rows_hash" : (last ? "ntt_pass_last" : "ntt_pass"));
+            hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            continue;
+        }
         if (first) {
             p.src = (const T *)job.src;
             p.src_div = job.src_div ? job.src_div : 1;

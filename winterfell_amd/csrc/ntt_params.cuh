@@ -40,6 +40,7 @@ struct PassParams {
     void *rh_leaves;
     // three-step passes (ntt_big.cuh): omega_R^e, e < R (Montgomery residues), the twiddles between the first and the second step
     const T *big_tab;
+    uint32_t vt_cols;         // vector tiles (ntt_pass<..., VT>): the number C of interleaved columns of the VT buffers, 0 = off
     uint32_t coset_order;     // first pass of a coset LDE: the cosets of a source tile run side by side on one XCD (ntt_pass)
 #ifdef WF_EXPERIMENTS
     // launch stagger (experiment, WF_NTT_STAGGER="ticks,mode"): the first workgroups of a launch start `generation` x ticks x 10 ns late
