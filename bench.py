@@ -645,7 +645,7 @@ def main():
         # the gfx950 correction + WRITE_SIZE, summed over the transform's launches); only valid for the profiled size
         traffic, valu, pmc_round = None, None, None
         try:
-            pmc_round = next(r for r in ("r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
+            pmc_round = next(r for r in ("r06", "r05", "r04", "r03", "r02", "r01") if os.path.exists(os.path.join(ROOT, "profiles", r, "bench_pmc_summary.json")))
             with open(os.path.join(ROOT, "profiles", pmc_round, "bench_pmc_summary.json")) as f:
                 pmf = json.load(f)
             if args.log_n == 24:
@@ -655,8 +655,9 @@ def main():
                 insts = 0.0
                 stall = {}
                 for kname, cs in pmf["kernels"].items():
-                    if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or kname.rstrip().split("(")[0].endswith(", true>"):
-                        continue                       # (the rows + leaves variant of the last pass belongs to the LDE, not to a transform)
+                    targs = kname.split("(")[0].split("<", 1)[-1].rstrip("> ").split(", ")    # F, LOG_A, LOG_B, LAST, TWTAB, PF, RH, VT
+                    if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or "true" in targs[6:]:
+                        continue                       # (the rows + leaves and vector-tile variants belong to the LDE, not to a transform)
                     per_transform = 1 if "ntt_pass<F64, 4, 4, true," in kname else 2       # the last pass once, the other shape twice
                     insts += per_transform * cs["SQ_INSTS_VALU"]["avg"] * 64 / n
                     for cname, cv in cs.items():           # every SQ / GRBM counter of the committed passes, summed over the transform's launches
@@ -809,7 +810,7 @@ def main():
             # FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE x2 per the gfx950 correction; tools/summarize_workloads_pmc.py)
             wl_traffic, wl_round = {}, None
             try:
-                wl_round = next(r for r in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
+                wl_round = next(r for r in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", r, "workloads_pmc_summary.json")))
                 with open(os.path.join(ROOT, "profiles", wl_round, "workloads_pmc_summary.json")) as f:
                     wl_traffic = json.load(f)["workloads"]
             except Exception:
