@@ -18,7 +18,8 @@ import winterfell_amd
 from winterfell_amd import crypto, fri as wfri, prover
 from winterfell_amd.math import fft, fields
 
-K = 2
+K = int(os.environ.get("WL_CALLS", "2"))
+SPIN_S = float(os.environ.get("WL_SPIN_S", "0"))
 ctx = winterfell_amd.default_context(0)
 rng = np.random.default_rng(1)
 manifest = []
@@ -32,6 +33,13 @@ def marker():
 def measure(name, fn):
     fn()                                   # warm-up: allocations, tables
     torch.cuda.synchronize()
+    if SPIN_S > 0:                         # steady clocks before the measured calls, as bench.py's legs have them (kernel-trace runs only:
+        import time                        # under --pmc every dispatch is serialised and a spin-up is minutes of counter collection)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < SPIN_S:
+            for _ in range(4):
+                fn()
+            torch.cuda.synchronize()
     marker()
     for _ in range(K):
         fn()
@@ -52,7 +60,7 @@ def lde_case(key, field, log_rows, cols, parts=1, hasher=None):
     torch.cuda.empty_cache()
 
 
-only = set(sys.argv[1:])
+only = set(a for a in sys.argv[1:])
 want = lambda k: not only or k in only
 if want("lde_small"):
     lde_case("2^20x4_b8_f64_blake3", fields.f64, 20, 4)

@@ -38,7 +38,7 @@ rocprofv3 --kernel-trace --stats -d "$RAW/kt" -o $R --output-format csv -- pytho
 cp "$RAW/kt/${R}_kernel_stats.csv" "$OUT/bench_kernel_stats.csv"
 python tools/kernel_trace_table.py "$RAW/kt/${R}_kernel_trace.csv" > "$OUT/bench_kernel_trace_by_size.csv"
 # 5. every fraction of the line from a kernel trace of the workloads (markers between them), beside the bench's own
-rocprofv3 --kernel-trace -d "$RAW/kt_wl" -o $R --output-format csv -- python tools/pmc_workloads.py > /dev/null 2>&1
+WL_SPIN_S=0.6 WL_CALLS=5 rocprofv3 --kernel-trace -d "$RAW/kt_wl" -o $R --output-format csv -- python tools/pmc_workloads.py > /dev/null 2>&1
 python tools/roofline_check.py "$RAW/kt_wl/${R}_kernel_trace.csv" gpurun_out/pmc_workloads_manifest.json "$OUT/bench_detail.json" "$OUT/workloads_pmc_summary.json" \
     "$OUT/workloads_kernel_table.json" > "$OUT/roofline_check.txt" 2>&1
 cat "$OUT/roofline_check.txt"
