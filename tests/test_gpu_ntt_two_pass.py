@@ -264,3 +264,72 @@ def test_wide_rows_hash_with_extension_columns_vs_oracle(oracle, c, D, log_n, bl
     assert np.array_equal(tree.leaves, o_leaves), "leaves"
     assert np.array_equal(tree.nodes, o_nodes), "nodes"
     assert "ntt_pass_last_rows_hash" in prof and "hash_rows_blake3" not in prof, prof
+
+
+# ---- vector tiles (round 6, ntt_pass<..., VT>): the coset LDE of a wide f64 trace on column-interleaved buffers ----
+VT_SHAPES = [          # (columns, log2 rows, blowup, takes vector tiles)
+    (32, 12, 4, True),      # two radix-64 passes, rows + leaves last pass, blowup 4 (the smallest blowup that takes vector tiles)
+    (32, 12, 16, True),     # blowup 16: no coset window in the first pass's tile order (linear order)
+    (32, 13, 64, True),     # the largest blowup the mode takes; radix 128 + 64
+    (64, 13, 8, True),      # 64 columns: row-major last pass (two groups of 32) + separate row hash
+    (96, 15, 4, True),      # 96 columns, radix 256 + 128: three column groups, tiles of 16 and of 32 columns
+    (48, 16, 8, True),      # 48 = 32 + a ragged group of 16 in the last pass; 2^16 = 256 x 256: the first pass has tiles of 16 columns
+    (32, 17, 8, False),     # plan 6, 6, 5: a radix-32 last pass has no vector-tile variant — position-major tiles
+    (40, 12, 8, False),     # not a multiple of the tile width
+    (32, 12, 2, False),     # blowup 2: the interleaving copy costs more than the shared twiddles save
+]
+
+
+@pytest.mark.parametrize("c,log_n,blowup,eligible", VT_SHAPES)
+def test_vector_tile_lde_vs_oracle_and_vs_position_major_tiles(oracle, c, log_n, blowup, eligible):
+    """wf_build_trace_commitment through the vector-tile passes, every polynomial, LDE word, leaf and node against the oracle, and the
+    same call on a context created with WF_LDE_VT=0 (position-major tiles, per-lane twiddle progressions): the same root"""
+    import os
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd._lib import Context
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    prof = _commit_and_compare(oracle, ctx, c, log_n, blowup)
+    assert ("vt_interleave" in prof) == eligible, prof
+    os.environ["WF_LDE_VT"] = "0"
+    try:
+        other = Context(ctx.device.index or 0)
+    finally:
+        del os.environ["WF_LDE_VT"]
+    try:
+        n = 1 << log_n
+        trace = oracle.f64_from_int(rand_field(c * 1000 + log_n, n * c)).reshape(c, n)
+        other.prof_enable(True)
+        _, tree2, _ = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(other.to_device(trace), 1, other), prover.StarkDomain(n, blowup))
+        prof2 = other.prof_collect()
+        other.prof_enable(False)
+        assert "vt_interleave" not in prof2
+        _, tree1, _ = prover.build_trace_commitment(crypto.Blake3_256, prover.ColMatrix(ctx.to_device(trace), 1, ctx), prover.StarkDomain(n, blowup))
+        assert np.array_equal(tree1.root(), tree2.root())
+    finally:
+        other.sync()
+        other.close()
+
+
+def test_vector_tiles_serve_evaluate_polys_over_and_other_hashers(oracle):
+    """RowMatrix::evaluate_polys_over (no leaves) and a Rescue commitment of a 32-column trace: the LDE comes from the vector-tile
+    passes (row-major last pass), the rows are hashed by the hasher's own kernel"""
+    import winterfell_amd
+    from winterfell_amd import crypto, prover
+    from winterfell_amd.math import fields
+    ctx = winterfell_amd.default_context()
+    c, log_n, b = 32, 12, 8
+    n = 1 << log_n
+    trace = oracle.f64_from_int(rand_field(77, n * c)).reshape(c, n)
+    ctx.prof_enable(True)
+    lde, tree, polys = prover.build_trace_commitment(crypto.Rp64_256, prover.ColMatrix(ctx.to_device(trace), 1, ctx), prover.StarkDomain(n, b))
+    prof = ctx.prof_collect()
+    ctx.prof_enable(False)
+    assert "vt_interleave" in prof, prof
+    o_polys, o_lde, o_leaves, o_nodes = oracle.build_trace_commitment(1, trace, b, fields.new(7), par=True)
+    assert np.array_equal(polys.to_host(), o_polys) and np.array_equal(lde.to_host(), o_lde)
+    assert np.array_equal(tree.nodes, o_nodes)
+    m = prover.RowMatrix.evaluate_polys_over(polys, b, fields.new(7)) if hasattr(prover.RowMatrix, "evaluate_polys_over") else None
+    if m is not None:
+        assert np.array_equal(m.to_host(), o_lde)
