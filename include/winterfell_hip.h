@@ -77,6 +77,8 @@ int wf_device_count(int *h_count);
  *                            transforms, batches of >= 8 vectors of 2^20 points, batches of >= 256 vectors of 2^21 points)
  *   WF_NTT_F64_TABLES=0|1    inter-pass twiddles of the f64 passes from one-word tables: never | wherever a table fits the cache budget;
  *                            unset = where measured faster (batches of vectors of at most 2^19 points)
+ *   WF_NTT_BT=0|1            block tiles for single three-pass f64 transforms (transposed first pass, tile-shared twiddles in the middle
+ *                            pass): never | wherever eligible; unset = 2^23-point transforms, where measured faster
  *   WF_LDE_VT=0              the coset LDE of a wide f64 trace (a multiple of 16 / 32 columns) runs on position-major tiles with per-lane
  *                            twiddle progressions instead of vector tiles with tile-shared twiddle rows (csrc/ntt_engine.cuh, VT)
  *   WF_ROWS_HASH_WIDE=0      rows of 9 .. 32 f64 columns are hashed by the separate row-hash kernel, not by the last NTT pass

@@ -333,3 +333,65 @@ def test_vector_tiles_serve_evaluate_polys_over_and_other_hashers(oracle):
     m = prover.RowMatrix.evaluate_polys_over(polys, b, fields.new(7)) if hasattr(prover.RowMatrix, "evaluate_polys_over") else None
     if m is not None:
         assert np.array_equal(m.to_host(), o_lde)
+
+
+# ---- block tiles (round 6, ntt_pass BT0): single three-pass f64 transforms with a transposed first pass ----
+@pytest.fixture(scope="module")
+def bt_ctx():
+    """a context with WF_NTT_BT=1 and WF_NTT_BIG=0: every single f64 transform of three radix 64 .. 256 passes takes block tiles"""
+    import os
+    import winterfell_amd
+    from winterfell_amd._lib import Context
+    old = {k: os.environ.get(k) for k in ("WF_NTT_BT", "WF_NTT_BIG")}
+    os.environ.update({"WF_NTT_BT": "1", "WF_NTT_BIG": "0"})
+    try:
+        ctx = Context(winterfell_amd.default_context().device.index or 0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    yield ctx
+    ctx.sync()
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n", [18, 19, 20, 21, 22, 23, 24])
+def test_block_tile_transform_vs_oracle(oracle, bt_ctx, log_n):
+    """math::fft evaluate / interpolate (math/src/fft/mod.rs:85-112, 264-295) through the block-tile plan, word for word against the
+    oracle's fft_in_place: forward, inverse (with its 1/n riding on the last pass's table), and the coset interpolation's post-scale"""
+    import torch
+    from winterfell_amd.math import fft, fields
+    n = 1 << log_n
+    p = oracle.f64_from_int(rand_field(7000 + log_n, n))
+    dp = bt_ctx.to_device(p)
+    ev = fft.evaluate_poly(dp.clone(), ctx=bt_ctx)
+    assert np.array_equal(bt_ctx.to_host(ev), oracle.evaluate_poly(p, par=True))
+    assert torch.equal(fft.interpolate_poly(ev, ctx=bt_ctx), dp)
+    assert np.array_equal(bt_ctx.to_host(fft.interpolate_poly(dp.clone(), ctx=bt_ctx)), oracle.interpolate_poly(p, par=True))
+    if log_n <= 20:
+        got = fft.interpolate_poly_with_offset(dp.clone(), None, fields.new(7), ctx=bt_ctx)
+        assert np.array_equal(bt_ctx.to_host(got), oracle.interpolate_poly_with_offset(p, fields.new(7)))
+
+
+def test_default_context_takes_block_tiles_at_2_23(oracle):
+    """the default rule: 2^23-point single transforms (-3 .. -5 % measured); the result is the standard plan's"""
+    import os
+    import torch
+    import winterfell_amd
+    from winterfell_amd._lib import Context
+    from winterfell_amd.math import fft
+    ctx = winterfell_amd.default_context()
+    d = ctx.to_device(oracle.f64_from_int(rand_field(23, 1 << 23)))
+    os.environ["WF_NTT_BT"] = "0"
+    try:
+        plain = Context(ctx.device.index or 0)
+    finally:
+        del os.environ["WF_NTT_BT"]
+    try:
+        assert torch.equal(fft.evaluate_poly(d.clone(), ctx=ctx), fft.evaluate_poly(d.clone(), ctx=plain))
+        assert torch.equal(fft.interpolate_poly(d.clone(), ctx=ctx), fft.interpolate_poly(d.clone(), ctx=plain))
+    finally:
+        plain.sync()
+        plain.close()

@@ -389,6 +389,8 @@ static int ctx_create(int device_id, bool own_stream, void *hip_stream, wf_ctx *
     if (const char *e = getenv("WF_NTT_COSET_ORDER")) ctx->coset_order = e[0] != '0';
     if (const char *e = getenv("WF_ROWS_HASH_WIDE")) ctx->rows_hash_wide = e[0] != '0';
     if (const char *e = getenv("WF_LDE_VT")) ctx->lde_vt = e[0] != '0';
+    if (const char *e = getenv("WF_VT_PREFETCH")) ctx->vt_prefetch = e[0] == '1';
+    if (const char *e = getenv("WF_NTT_BT")) ctx->ntt_bt = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
     if (const char *e = getenv("WF_NTT_F64_TABLES")) ctx->f64_tw_tables = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : -1);
     if (const char *e = getenv("WF_NTT_BIG")) ctx->ntt_big = e[0] == '0' ? 0 : (e[0] == '1' ? 1 : (e[0] == '2' ? 2 : -1));
     // WF_NTT_PLAN="L:r0,r1,...": a pass plan for transforms of 2^L points (tools/time_batch_ntt.py measures alternatives with it).

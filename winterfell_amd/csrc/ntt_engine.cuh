@@ -91,9 +91,19 @@ namespace {
 // values per tile as well (one look-up per lane into LDS, one product per element instead of two).  Per element of a non-last pass:
 // 114 -> ~86 VALU instructions, first pass of an LDE 150 -> ~109.  The last pass only changes its lane <-> (row, column) assignment and
 // its source address (columns are the contiguous axis of every VT buffer); its outputs — row-major rows, leaves — are as before.
-template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false, bool VT = false>
+//
+// Block tiles for a SINGLE transform of three passes (round 6, VTM = 2 for its first pass): the same sharing for the MIDDLE pass of one
+// vector.  Its twiddles omega^(k1 a2) do not depend on the block k0 (the first pass's output digit), so a tile of 16 consecutive BLOCKS at
+// one a2 shares them — if the blocks are the contiguous axis.  The first pass therefore stores its outputs transposed, T[rem0 R0 + k0]
+// (lanes of step 2 are dealt k_a-fastest so that a lane group's 16 consecutive k0 are one 128-byte run; the exchange buffer's columns are
+// rotated by (32 / B) k_a for that read pattern), the middle pass IS the vector-tile kernel with C = R0 "columns" and no coset dimension, in
+// place, and the last pass reads [(k1 S1 + a2) R0 + k0] with columns fastest (p.bt) and stores in natural order as always.
+template <class F, int LOG_A, int LOG_B, bool LAST, bool TWTAB, bool PF, bool RH = false, int VTM = 0>
 __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PF ? NTT_PF_WAVES : (F::USE_L24 ? NTT_MIN_WAVES : 1)))) void ntt_pass(PassParams<typename F::T> p) {
-    static_assert(!VT || (F::USE_L24 && !PF && !TWTAB && LOG_B >= 3), "vector tiles: f64 passes of radix 64 .. 256");
+    constexpr bool VT = VTM == 1;       // vector tiles (and the block-tile plan's middle and last pass)
+    constexpr bool BT0 = VTM == 2;      // the block-tile plan's first pass: standard tile, transposed output
+    static_assert(!VT || (F::USE_L24 && !TWTAB && LOG_B >= 3 && !(PF && LAST)), "vector tiles: f64 passes of radix 64 .. 256");
+    static_assert(!BT0 || (F::USE_L24 && !PF && !TWTAB && !LAST && !RH && LOG_B >= 3), "block-transposing first pass: f64, radix 64 .. 256");
     static_assert(!(LAST && TWTAB), "the last pass has no inter-pass twiddles");
     static_assert(!RH || (LAST && !PF && F::USE_L24 && LOG_B >= 3), "rows mode: f64 last passes of radix 64 / 128 / 256");
     static_assert(!(PF && TWTAB), "the table kernel's step-2 loads would drain the prefetch (in-order vm counter)");
@@ -120,6 +130,9 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     auto idx_nl = [](int ka, int col) -> int { return ka * ROW_NL + (col ^ ((ka & 1) << 4)); };
     auto idx_l = [](int ka, int t, int b) -> int { return (ka * TC + t) * ROW_L + (b ^ ((t ^ ka) & (B - 1))); };
 #endif
+    // BT0: step 2 reads with k_a fastest across lanes; rotating a row's columns by (32 / B) k_a puts the B k_a x 32 / B columns of a
+    // half-wave on 32 different 8-byte banks (rows are 256 elements = a multiple of the 32 banks), and step 1's writes stay linear
+    auto idx_bt = [](int ka, int col) -> int { return ka * (B * TC) + ((col + (32 / B) * ka) & (B * TC - 1)); };
     constexpr int LDS_ELEMS = (B == 1) ? 1 : (LAST ? A * TC * ROW_L : A * ROW_NL);
     __shared__ T lds[LDS_ELEMS];
     // f64: the intra-pass twiddle rows (four words each, l24.cuh) a workgroup needs — omega_R^(k_a b), R rows — are copied to LDS
@@ -135,8 +148,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     // VT: the tile's inter-pass twiddle rows take wlds' place once step 1 is through with it, the coset pre-scale factors of a first pass
     // sit in the exchange buffer until step 1 has read them (one more barrier each): no LDS beyond the 40 KiB of a radix-256 pass, i.e.
     // four workgroups per CU (with arrays of their own, 50 KiB and three: measured 2^22 x 32 LDE passes 7.66 ms)
-    uint4 *const vt_rows = wlds;
-    T *const vt_ps = lds;
+    // The persistent prefetching variant (PF) walks tiles in a loop: it keeps wlds for every tile's step 1 and holds the rows and the
+    // pre-scale factors in arrays of their own (50 KiB, three workgroups per CU — the occupancy its 132 VGPRs allow anyway).
+    __shared__ uint4 vt_rows_own[(VT && !LAST && PF) ? 2 * (1 << LOG_R) : 1];
+    __shared__ T vt_ps_own[(VT && !LAST && PF) ? (1 << LOG_R) : 1];
+    uint4 *const vt_rows = PF ? vt_rows_own : wlds;
+    T *const vt_ps = PF ? vt_ps_own : lds;
 
     int tid = threadIdx.x;
 #if defined(WF_EXPERIMENTS) && defined(NTT_EXTRA_LDS)      // occupancy experiment (tools/build_variant.sh): bytes of LDS a workgroup holds on top of what it needs
@@ -207,9 +224,13 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     // (VT: the columns are the contiguous axis of every buffer, so the last pass deals its lanes like a non-last one)
     if (!LAST || VT) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
     // VT non-last pass: tile -> (position column c, column group g of TC columns, coset u); whole tiles only (checked on the host)
-    uint64_t vt_c = 0;
-    uint32_t vt_g = 0, vt_u = 0;
-    auto vt_tile = [&](uint64_t tl) {
+    uint64_t vt_c = 0, vtn_c = 0;                // (vtn_*: the prefetched next tile of the persistent variant)
+    uint32_t vt_g = 0, vt_u = 0, vtn_g = 0, vtn_u = 0;
+    uint64_t &vt_c0r = vt_c;
+    uint32_t &vt_g0r = vt_g, &vt_u0r = vt_u;
+    uint64_t vt_tiles = 0;
+    if constexpr (VT && !LAST) vt_tiles = p.vt_tiles;
+    auto vt_tile = [&](uint64_t tl, uint64_t &vt_c, uint32_t &vt_g, uint32_t &vt_u) {
         const uint32_t b = 1u << p.rm_log_b, gt = p.vt_cols / TC;
         const uint64_t full = (ncols * gt * b) / 64 * 64;
         uint64_t pair;
@@ -226,10 +247,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         vt_g = (uint32_t)(pair - vt_c * gt);
     };
     // issue the loads of this lane's A inputs of tile `tile` (no wait); also returns what step 1 needs to know about them
-    auto load_inputs = [&](uint64_t tile, T (&xin)[A], bool &active, uint64_t &v, uint64_t &base) {
+    auto load_inputs = [&](uint64_t tile, T (&xin)[A], bool &active, uint64_t &v, uint64_t &base, bool nxt) {
         if constexpr (VT && !LAST) {
             // element (column bc, coset u, position j) lives at [(u n + j) C + bc]; the first pass reads the polynomials: [j C + bc]
-            vt_tile(tile);
+            uint64_t &vt_c = nxt ? vtn_c : vt_c0r;
+            uint32_t &vt_g = nxt ? vtn_g : vt_g0r, &vt_u = nxt ? vtn_u : vt_u0r;
+            vt_tile(tile, vt_c, vt_g, vt_u);
             const uint32_t bc = vt_g * TC + (uint32_t)t1;
             v = ((uint64_t)bc << p.rm_log_b) + vt_u;
             const uint64_t rem = vt_c & ((1ull << log_s) - 1);
@@ -265,7 +288,10 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         if constexpr (VT) {
             // last pass on the column-interleaved ping buffer: [(u n + position) C + bc], positions base + b1 + B a
             if (active) {
-                const T *ptr = p.src + (((uint64_t)u1 << L) + base + (uint64_t)b1) * p.vt_cols + bc1;
+                // block-tile plan (p.bt): column index cc = k0 + R0 k1; the lane's inputs are a2 = b1 + B a of [(k1 S1 + a2) R0 + k0]
+                const uint64_t pos0 = p.bt ? ((c >> p.log_r[0]) << (L - p.log_r[0] - p.log_r[1])) : (((uint64_t)u1 << L) + base);
+                const uint32_t bcx = p.bt ? ((uint32_t)c & ((1u << p.log_r[0]) - 1)) : bc1;
+                const T *ptr = p.src + (pos0 + (uint64_t)b1) * p.vt_cols + bcx;
                 const uint64_t istep = (uint64_t)B * p.vt_cols;
 #pragma unroll
                 for (int a = 0; a < A; a++) {
@@ -298,7 +324,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         }
     };
 
-    const uint64_t ntiles = (total_cols + TC - 1) / TC;
+    const uint64_t ntiles = (VT && !LAST) ? vt_tiles : (total_cols + TC - 1) / TC;
     uint64_t tile = blockIdx.x;
     if constexpr (!LAST && !PF) {
         // First pass of a coset LDE (src_div = blowup b cosets per input column): the b tiles that read the SAME source tile — cosets
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
         // bank conflicts for the last pass's lanes measured SLOWER: 73 against 64 us for that pass)
         for (int i = threadIdx.x; i < 2 * WROWS; i += 256) wlds[i] = rows[2 * ((i >> 1) << (8 - LOG_R)) + (i & 1)];
     }
-    load_inputs(tile, x, active, v1, base1);
+    load_inputs(tile, x, active, v1, base1, false);
     uint64_t vt_w = 0;
     if constexpr (VT && !LAST) {
         // the tile's R inter-pass twiddles omega_n^((k' rem) mult), one per lane, expanded to the four-word rows of the exit (l24.cuh:
@@ -357,7 +383,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     if constexpr (PF) {
         // the same for everything derived from the lane index (LDS addresses, table addresses, b1 / t1 / t2 / q2)
         asm volatile("" : "+v"(tid));
-        if (!LAST) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
+        if (!LAST || VT) { t1 = tid % TC; b1 = tid / TC; } else { b1 = tid % B; t1 = tid / B; }
     }
     const uint64_t cc0 = tile * TC;
     // ---- step 1: A-point DFT over the high half of the pass digit ---------------------------------
@@ -418,7 +444,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
                     } else {
                         val = l24::fold_lazy(l24::mul4_one(y));
                     }
-                    if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
+                    if constexpr (BT0) lds[idx_bt(ka, b1 * TC + t1)] = val;
+                    else if (!LAST) lds[idx_nl(ka, b1 * TC + t1)] = val;
                     else lds[idx_l(ka, t1, b1)] = val;
                 } else {
                     x[i] = l24::fold(l24::mul4_one(y));
@@ -452,8 +479,8 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     }
 
     // ---- step 2: B-point DFT(s) over the low half, inter-pass twiddle, store -----------------------
-    const int t2 = (B > 1) ? tid % TC : t1;
-    const int q2 = (B > 1) ? tid / TC : 0;
+    const int t2 = BT0 ? tid / B : ((B > 1) ? tid % TC : t1);      // BT0: k_a fastest across lanes (transposed, coalesced stores)
+    const int q2 = BT0 ? tid % B : ((B > 1) ? tid / TC : 0);
     const uint64_t cc = cc0 + t2;
     const uint64_t next_tile = tile + gridDim.x;
     const bool more = PF && next_tile < ntiles;
@@ -476,7 +503,26 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             pf_stp[g] = series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, ((uint32_t)A * r32) << log_mult);
         }
     }
-    if (more) load_inputs(next_tile, xn, active_n, vn, basen);
+    uint64_t vt_w_n = 0;
+    if constexpr (PF && VT && !LAST) {
+        if (more) {
+            // the NEXT tile's twiddle and pre-scale look-ups go out before its data loads (the vm counter retires in order: whoever
+            // waits for these does not wait for the sixteen loads behind them); step 1 of this tile is through with vt_ps
+            uint64_t nc;
+            uint32_t ng, nu;
+            vt_tile(next_tile, nc, ng, nu);
+            const uint32_t r32n = (uint32_t)(nc & ((1ull << log_s0) - 1));
+            if (tid < (1 << LOG_R)) {
+                vt_w_n = gl::to_int(series_at32<F>(p.w_lo, p.w_hi, p.w_log_lo, ((uint32_t)tid * r32n) << log_mult));
+                if (p.pre_lo != nullptr && p.pass == 0) {
+                    const T *plo = p.pre_lo + nu * p.pre_lo_stride, *phi = p.pre_hi + nu * p.pre_hi_stride;
+                    const uint64_t base_t = ((nc >> log_s0) << (log_s0 + LOG_R)) + r32n;
+                    vt_ps[tid] = series_at32<F>(plo, phi, p.pre_log_lo, (uint32_t)(base_t + ((uint64_t)tid << log_s0)));
+                }
+            }
+        }
+    }
+    if (more) load_inputs(next_tile, xn, active_n, vn, basen, true);
     if ((VT && !LAST) || cc < total_cols) {
     uint64_t v, c;
     uint32_t bc2, u2;
@@ -510,6 +556,10 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
             // the column-interleaved ping buffer: [(u n + position) C + bc]
             o_ptr = o_ptr0 = p.dst + (((uint64_t)u2 << L) + base_nl + ((uint64_t)kbase << log_s)) * p.vt_cols + bc2;
             o_step = (int64_t)(((uint64_t)p.vt_cols) << log_s);
+        } else if constexpr (BT0) {
+            // transposed: output digit k0 of column rem0 (= c: the first pass has one block) at [rem0 R0 + k0]
+            o_ptr = o_ptr0 = p.dst + ((c << LOG_R) + kbase);
+            o_step = 1;
         } else if constexpr (!LAST) {
             o_ptr = o_ptr0 = dst + (base_nl + ((uint64_t)kbase << log_s)) * p.dst_es;
             o_step = (int64_t)(((uint64_t)p.dst_es) << log_s);
@@ -644,6 +694,7 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
 #pragma unroll
             for (int bb = 0; bb < B; bb++) {
                 if constexpr (RH) y[bb] = yall[g][bb];
+                else if constexpr (BT0) y[bb] = lds[idx_bt(ka, bb * TC + t2)];
                 else if (!LAST) y[bb] = lds[idx_nl(ka, bb * TC + t2)];
                 else y[bb] = lds[idx_l(ka, t2, bb)];
             }
@@ -776,6 +827,12 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     v1 = vn;
     base1 = basen;
     tile = next_tile;
+    if constexpr (PF && VT && !LAST) {
+        vt_c = vtn_c;
+        vt_g = vtn_g;
+        vt_u = vtn_u;
+        vt_w = vt_w_n;
+    }
     }   // tiles
 }
 
@@ -794,13 +851,17 @@ template <class F, int LA, int LB>
 constexpr bool has_rows_variant() { return F::USE_L24 && (LA == LB || LA == LB + 1) && LB >= 3; }
 
 template <class F, int LA, int LB>
-auto pick(bool last, bool twtab, bool pf, bool rh = false, bool vt = false) -> void (*)(PassParams<typename F::T>) {
+auto pick(bool last, bool twtab, bool pf, bool rh = false, int vt = 0) -> void (*)(PassParams<typename F::T>) {
     typedef void (*fn)(PassParams<typename F::T>);
     if constexpr (has_rows_variant<F, LA, LB>()) {
 #ifndef WF_NO_VECTOR_TILES
-        if (vt && rh && last) return (fn)ntt_pass<F, LA, LB, true, false, false, true, true>;
-        if (vt && last) return (fn)ntt_pass<F, LA, LB, true, false, false, false, true>;
-        if (vt) return (fn)ntt_pass<F, LA, LB, false, false, false, false, true>;
+        if (vt == 1 && rh && last) return (fn)ntt_pass<F, LA, LB, true, false, false, true, 1>;
+        if (vt == 1 && last) return (fn)ntt_pass<F, LA, LB, true, false, false, false, 1>;
+#ifdef WF_EXPERIMENTS      // the persistent prefetching variant of the vector-tile passes: measured slower (see ntt_run), experiment builds only
+        if (vt == 1 && pf) return (fn)ntt_pass<F, LA, LB, false, false, true, false, 1>;
+#endif
+        if (vt == 1) return (fn)ntt_pass<F, LA, LB, false, false, false, false, 1>;
+        if (vt == 2 && !last) return (fn)ntt_pass<F, LA, LB, false, false, false, false, 2>;
 #endif
         if (rh && last) return (fn)ntt_pass<F, LA, LB, true, false, false, true>;
     }
@@ -812,7 +873,7 @@ auto pick(bool last, bool twtab, bool pf, bool rh = false, bool vt = false) -> v
 }
 
 template <class F>
-auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false, bool vt = false) -> void (*)(PassParams<typename F::T>) {
+auto kernel_for(uint32_t r, bool last, bool twtab, bool pf, bool rh = false, int vt = 0) -> void (*)(PassParams<typename F::T>) {
     switch (r) {
         case 1: return pick<F, 1, 0>(last, twtab, pf);
         case 2: return pick<F, 1, 1>(last, twtab, pf);
@@ -1036,6 +1097,15 @@ static int launch_big_pass(wf_ctx *ctx, const PassParams<uint64_t> &p, uint32_t 
     }
 }
 
+static inline bool vt_pf_enabled(const wf_ctx *ctx) {
+#ifdef WF_EXPERIMENTS
+    return ctx->vt_prefetch;
+#else
+    (void)ctx;
+    return false;
+#endif
+}
+
 template <class HF>
 static int ntt_run(wf_ctx *ctx, const NttJob &job) {
     typedef typename HF::Dev F;
@@ -1177,6 +1247,23 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
         }
 #endif
     }
+    // Block tiles for a single three-pass f64 transform (ntt_pass, BT0): first pass stores transposed, the middle pass is the vector-tile
+    // kernel over C = R0 blocks with its twiddles shared per tile, the last pass reads columns-fastest.  Measured (tools/time_bt.py, three
+    // boxes, profiles/r06/block_tiles_ab.txt): the middle pass 55.2 against 59.0 us at 2^24 — a third fewer instructions, but latency
+    // bound at four waves per SIMD — while the transposing first pass and the strided last pass each give ~1 us back: 2^24 166.0 against
+    // 163.8 us (+1 %), 2^23 95.9-98.1 against 101.1-102.5 us (-3 .. -5 %), nothing below.  Default: 2^23 only.  WF_NTT_BT=0 / 1: never /
+    // wherever eligible.
+    bool bt = false;
+    if constexpr (F::USE_L24) {
+#ifndef WF_NO_VECTOR_TILES
+        bt = !vt && !big && ctx->ntt_bt != 0 && (ctx->ntt_bt > 0 || L == 23) && job.nvec == 1 && p.npass == 3 && job.src_div <= 1 && job.src_inner <= 1 &&
+             job.dst_inner <= 1 && job.src_es == 1 && job.dst_es == 1 && !job.rowmajor && !rh;
+        for (uint32_t q = 0; bt && q < 3; q++) {
+            const uint32_t r = p.log_r[q], tc = 256u >> log_b_for(r);
+            bt = r >= 6 && r <= 8 && (n >> r) % tc == 0 && (q == 0 || (1u << p.log_r[0]) % tc == 0);
+        }
+#endif
+    }
     T *tmp = nullptr;
     if (p.npass > 1) {
         void *t;
@@ -1207,8 +1294,24 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
             const uint32_t Tc = 256u >> log_b_for(r);
             uint64_t blocks;
             const bool rh_pass = rh && last;
+            bool pfv = false;
             if (!last) {
                 blocks = ((n >> r) * (p.vt_cols / Tc)) << job.rm_log_b;
+                p.vt_tiles = blocks;
+                // The persistent prefetching variant (the next tile's loads in flight behind this tile's arithmetic; -DWF_EXPERIMENTS builds with
+                // WF_VT_PREFETCH=1).  With a third fewer instructions the vector-tile passes are latency bound at four waves per SIMD (a wave
+                // idles ~3.5 us per tile on its loads: 3.3 ps per element and pass measured against 2.3 ps of issue time), which is what the
+                // prefetch was built to hide — but its 134 VGPRs and 50 KiB of LDS leave three waves per SIMD, and it LOSES: LDE passes of
+                // 2^22 x 32 columns 10.25 against 8.26 ms, the block-tile middle pass of a 2^24 transform 61.0 against 55.2 us (round 6,
+                // profiles/r06/vector_tiles_prefetch_ab.txt) — the same verdict as round 2's prefetching variant of the plain pass.
+                if (vt_pf_enabled(ctx)) {
+                    uint32_t resident = 0;
+                    WF_TRY(wf_resident_blocks(ctx, (const void *)kernel_for<F>(r, false, false, true, false, 1), &resident));
+                    if (resident > 0 && blocks >= 4ull * resident) {
+                        pfv = true;
+                        blocks = resident;
+                    }
+                }
             } else {
                 uint64_t total_cols;
                 if (rh_pass) total_cols = (n >> r) << (job.rm_log_b + rh_log_cp);
@@ -1219,7 +1322,7 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
                 blocks = (total_cols + Tc - 1) / Tc;
             }
             if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
-            auto k = kernel_for<F>(r, last, false, false, rh_pass, true);
+            auto k = kernel_for<F>(r, last, false, pfv, rh_pass, 1);
             wf_prof_begin(ctx, rh_pass ? "ntt_pass_last_rows_hash" : (last ? "ntt_pass_last" : "ntt_pass"));
             hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
             wf_prof_end(ctx);
@@ -1284,6 +1387,38 @@ static int ntt_run(wf_ctx *ctx, const NttJob &job) {
                 WF_TRY(launch_big_pass<HF>(ctx, p, r, last, cols));
                 continue;
             }
+        }
+        if (bt) {
+            const uint32_t Tc = 256u >> log_b_for(r), R0 = 1u << p.log_r[0];
+            p.rowmajor = 0;
+            p.coset_order = 0;
+            p.tw_tab = nullptr;
+            p.tw_pair = 0;
+            p.bt = last ? 1 : 0;
+            p.vt_cols = q == 0 ? 0 : R0;
+            uint64_t blocks = (n >> r) / Tc;                                              // first and last pass: the standard tiling
+            bool pfv = false;
+            if (q == 1) {
+                p.src = tmp;                                                               // in place on the transposed buffer
+                p.dst = tmp;
+                blocks = (n >> (p.log_r[0] + r)) * (R0 / Tc);                              // a2 positions x groups of Tc blocks
+                p.vt_tiles = blocks;
+                if (vt_pf_enabled(ctx)) {
+                    uint32_t resident = 0;
+                    WF_TRY(wf_resident_blocks(ctx, (const void *)kernel_for<F>(r, false, false, true, false, 1), &resident));
+                    if (resident > 0 && blocks >= 4ull * resident) {
+                        pfv = true;
+                        blocks = resident;
+                    }
+                }
+            }
+            if (blocks > 0x7fffffffull) return WF_ERR_DOMAIN_TOO_LARGE;
+            auto k = kernel_for<F>(r, last, false, pfv, false, q == 0 ? 2 : 1);
+            wf_prof_begin(ctx, last ? "ntt_pass_last" : "ntt_pass");
+            hipLaunchKernelGGL(k, dim3((uint32_t)blocks), dim3(256), 0, ctx->stream, p);
+            wf_prof_end(ctx);
+            WF_HIP(hipGetLastError());
+            continue;
         }
         const uint32_t Tc = 256u >> log_b_for(r);
         uint64_t total_cols = (n >> r) * (uint64_t)job.nvec;

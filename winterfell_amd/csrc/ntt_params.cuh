@@ -40,6 +40,8 @@ struct PassParams {
     void *rh_leaves;
     // three-step passes (ntt_big.cuh): omega_R^e, e < R (Montgomery residues), the twiddles between the first and the second step
     const T *big_tab;
+    uint32_t bt;              // block-tile plan of a single transform: the last pass reads [(k1 S1 + a2) R0 + k0] (ntt_pass, BT0)
+    uint64_t vt_tiles;        // number of tiles of a non-last vector-tile pass (the persistent variant walks them)
     uint32_t vt_cols;         // vector tiles (ntt_pass<..., VT>): the number C of interleaved columns of the VT buffers, 0 = off
     uint32_t coset_order;     // first pass of a coset LDE: the cosets of a source tile run side by side on one XCD (ntt_pass)
 #ifdef WF_EXPERIMENTS

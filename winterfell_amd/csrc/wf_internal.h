@@ -109,6 +109,10 @@ struct wf_ctx {
     // WF_NTT_F64_TABLES=0|1 (unset: where measured faster): the f64 passes take their inter-pass twiddles from one-word tables (one product
     // per element) instead of from the per-lane progression (two products per element); ntt_engine.cuh get_pass_twiddles
     int f64_tw_tables = -1;        // -1: the rule of get_pass_twiddles (batches of <= 2^19-point vectors)
+    // WF_NTT_BT=0|1 (unset: 2^23-point transforms): block tiles for single three-pass f64 transforms (ntt_engine.cuh, BT0)
+    int ntt_bt = -1;
+    // WF_VT_PREFETCH=1 (-DWF_EXPERIMENTS builds only): the persistent prefetching variant of the non-last vector-tile passes; measured slower
+    bool vt_prefetch = false;
     // WF_LDE_VT=0 (read once at context creation): no vector tiles for the coset LDE of wide f64 traces (ntt_pass<..., VT>; A/B measurements)
     bool lde_vt = true;
     // WF_ROWS_HASH_WIDE=0 (read once at context creation): rows wider than one 8-column group are hashed by the separate row-hash
