@@ -656,7 +656,7 @@ def main():
                 stall = {}
                 for kname, cs in pmf["kernels"].items():
                     targs = kname.split("(")[0].split("<", 1)[-1].rstrip("> ").split(", ")    # F, LOG_A, LOG_B, LAST, TWTAB, PF, RH, VT
-                    if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or "true" in targs[6:]:
+                    if "ntt_pass<F64, 4, 4" not in kname or "SQ_INSTS_VALU" not in cs or any(a not in ("false", "0") for a in targs[6:]):
                         continue                       # (the rows + leaves and vector-tile variants belong to the LDE, not to a transform)
                     per_transform = 1 if "ntt_pass<F64, 4, 4, true," in kname else 2       # the last pass once, the other shape twice
                     insts += per_transform * cs["SQ_INSTS_VALU"]["avg"] * 64 / n

@@ -27,7 +27,7 @@ def traffic(last, twtab):
     (ntt_pass<F64, LOG_A, LOG_B, LAST, TWTAB, PF = false, RH = false>), and how many launches the counter pass saw."""
     tot, launches = 0.0, 0
     for k, cs in kernels.items():
-        m = re.search(r"ntt_pass<F64, 4, 4, (true|false), (true|false), false(?:, false)*>", k)      # PF, RH (round 3) and VT (round 6) are false for a plain transform
+        m = re.search(r"ntt_pass<F64, 4, 4, (true|false), (true|false), false(?:, false)*(?:, 0)?>", k)      # PF, RH (round 3) are false and the tile mode (round 6) is 0 for a plain transform
         if m and (m.group(1) == "true") == last and (m.group(2) == "true") == twtab and "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
             tot = (2 * cs["FETCH_SIZE"]["avg"] + cs["WRITE_SIZE"]["avg"]) * 1024
             launches = cs["FETCH_SIZE"]["launches"]

@@ -1,6 +1,8 @@
+"""Pass plans for a single 2^24-point f64 transform, kernel by kernel (WF_NTT_PLAN, one context per plan): every radix <= 256 pass costs
+~46-55 us whatever its radix, so four radix-64 passes (213-234 us) lose to three radix-256 passes (171 us).  python tools/time_plans_2p24.py"""
 import os, sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import winterfell_amd
 from winterfell_amd._lib import Context
 from winterfell_amd.math import fft
