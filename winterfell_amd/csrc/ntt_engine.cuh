@@ -226,8 +226,6 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     // VT non-last pass: tile -> (position column c, column group g of TC columns, coset u); whole tiles only (checked on the host)
     uint64_t vt_c = 0, vtn_c = 0;                // (vtn_*: the prefetched next tile of the persistent variant)
     uint32_t vt_g = 0, vt_u = 0, vtn_g = 0, vtn_u = 0;
-    uint64_t &vt_c0r = vt_c;
-    uint32_t &vt_g0r = vt_g, &vt_u0r = vt_u;
     uint64_t vt_tiles = 0;
     if constexpr (VT && !LAST) vt_tiles = p.vt_tiles;
     auto vt_tile = [&](uint64_t tl, uint64_t &vt_c, uint32_t &vt_g, uint32_t &vt_u) {
@@ -250,15 +248,24 @@ __global__ __launch_bounds__(256) NTT_WAVES_ATTR __attribute__((amdgpu_waves_per
     auto load_inputs = [&](uint64_t tile, T (&xin)[A], bool &active, uint64_t &v, uint64_t &base, bool nxt) {
         if constexpr (VT && !LAST) {
             // element (column bc, coset u, position j) lives at [(u n + j) C + bc]; the first pass reads the polynomials: [j C + bc]
-            uint64_t &vt_c = nxt ? vtn_c : vt_c0r;
-            uint32_t &vt_g = nxt ? vtn_g : vt_g0r, &vt_u = nxt ? vtn_u : vt_u0r;
-            vt_tile(tile, vt_c, vt_g, vt_u);
-            const uint32_t bc = vt_g * TC + (uint32_t)t1;
-            v = ((uint64_t)bc << p.rm_log_b) + vt_u;
-            const uint64_t rem = vt_c & ((1ull << log_s) - 1);
-            base = ((vt_c >> log_s) << (log_s + LOG_R)) + rem;
+            uint64_t tc;                           // this tile's coordinates: kept for step 2 (vt_*), or for the next iteration (vtn_*)
+            uint32_t tg, tu;
+            vt_tile(tile, tc, tg, tu);
+            if (nxt) {
+                vtn_c = tc;
+                vtn_g = tg;
+                vtn_u = tu;
+            } else {
+                vt_c = tc;
+                vt_g = tg;
+                vt_u = tu;
+            }
+            const uint32_t bc = tg * TC + (uint32_t)t1;
+            v = ((uint64_t)bc << p.rm_log_b) + tu;
+            const uint64_t rem = tc & ((1ull << log_s) - 1);
+            base = ((tc >> log_s) << (log_s + LOG_R)) + rem;
             active = true;
-            const T *ptr = p.src + ((p.pass ? ((uint64_t)vt_u << L) : 0ull) + base + ((uint64_t)b1 << log_s)) * p.vt_cols + bc;
+            const T *ptr = p.src + ((p.pass ? ((uint64_t)tu << L) : 0ull) + base + ((uint64_t)b1 << log_s)) * p.vt_cols + bc;
             const uint64_t istep = ((uint64_t)B << log_s) * p.vt_cols;
 #pragma unroll
             for (int a = 0; a < A; a++) {
