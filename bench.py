@@ -945,8 +945,8 @@ def main():
                 ex.update(sharded)
             out["extra"] = ex
 
-        if not args.no_cpu_baseline:
-            # ---- CPU baseline (rank 0, N = 1 semantics): the oracle's OpenMP restatement of the reference's `concurrent`
+        if not args.no_cpu_baseline and world == 1:
+            # ---- CPU baseline (rank 0, N = 1 only: the N > 1 runs are about scaling, and the other ranks would wait for it): the oracle's OpenMP restatement of the reference's `concurrent`
             # (Rayon) algorithms, on this host.  As in math/benches/fft.rs the twiddles are computed once, outside the timed
             # body; the transform runs in place at the bench's own size.  The reference's 4-step
             # transposes are single-threaded (math/src/fft/concurrent.rs:177-218) and so are ours.
